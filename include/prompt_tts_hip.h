@@ -1,0 +1,208 @@
+/*
+ * prompt_tts_hip.h -- C-ABI of the MI355X (gfx950) hot-path library for khaidoan25/prompt-tts.
+ *
+ * The reference has no FFI of its own (it is pure Python on ATen); each entry point below
+ * replaces the ATen ops that one reference call site dispatches, cited as file:line relative to
+ * the reference root.  Conventions (all entry points):
+ *   - plain pointers and sizes only; the CALLER owns every buffer; nothing here allocates,
+ *     frees or synchronises; every launch goes to the `stream` argument only;
+ *   - activations are token-major ("channels-last"): a (B, N, C) tensor is a row-major
+ *     [B*N][C] matrix; `dtype` selects the storage/compute element type of activations and
+ *     weight shadows: PT_F32 (parity mode, exact-f32 MFMA) or PT_BF16 (bf16 MFMA, f32 accumulate);
+ *   - statistics, biases, LSE, losses, master weights and ALL weight gradients are f32;
+ *   - return value 0 = launched; <0 = refused before any launch (see pt_status); never throws.
+ *   - re-entrant and thread-safe: no global mutable state.
+ */
+#ifndef PROMPT_TTS_HIP_H
+#define PROMPT_TTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pt_stream;            /* a hipStream_t */
+
+enum pt_status { PT_OK = 0, PT_ERR_SHAPE = -1, PT_ERR_DTYPE = -2, PT_ERR_LAUNCH = -3, PT_ERR_ALIGN = -4,
+                 PT_ERR_ARG = -5 };
+enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
+
+int pt_abi_version(void);                       /* bumps on any signature change */
+const char* pt_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
+ * An operand is a "virtual matrix" V[row][col] (pt_operand) read either with the reduction index
+ * on its columns (trans = 0) or on its rows (trans = 1; LDS-transposed fragment reads).
+ * Replaces: nn.Linear / Conv1d(k=1) / Conv1d(k=3, stride 1|2) / nearest-x2-upsample+Conv1d and
+ * their autograd backward (tts/ldm/resnet.py:34,73,171,193,226-228; transformer_1d.py:134;
+ * unet_1d_condition.py:193-195,410-412; diffusers Attention.to_q/k/v/to_out, FeedForward).
+ * ---------------------------------------------------------------------------------------------- */
+enum pt_vkind {
+  PT_V_PLAIN = 0,   /* V[r][c] = p[r*ld + c]                                     (c < cols)          */
+  PT_V_CONCAT = 1,  /* c < c_split ? p[r*ld + c] : p2[r*ld2 + c - c_split]        (channel concat)    */
+  PT_V_CONV = 2,    /* c = tap*cin + ci ; r = b*n_out + n ; V = p[(b*n_in + src(n,tap))*ld + ci] or 0  */
+  PT_V_WFLIP = 3    /* r = tap*cout + co ; V = p[(co*3 + (2-tap))*ld_tap + c]  (conv dgrad weights)    */
+};
+enum pt_rowmap {    /* src(n, tap) for PT_V_CONV; "invalid" rows read as zero */
+  PT_MAP_S1 = 0,        /* n + tap - 1                    (conv k3 stride 1, pad 1)                    */
+  PT_MAP_S2 = 1,        /* 2n + tap - 1                   (conv k3 stride 2, pad 1)                    */
+  PT_MAP_UP2 = 2,       /* (n + tap - 1) >> 1 over 2*n_in (nearest x2 upsample, then conv k3)          */
+  PT_MAP_S2_DGRAD = 3   /* u = n + tap - 1 ; u even ? u/2 : invalid   (dgrad of the stride-2 conv)     */
+};
+
+typedef struct pt_operand {
+  const void* p;  int64_t ld;
+  const void* p2; int64_t ld2; int64_t c_split;     /* PT_V_CONCAT */
+  int32_t kind;   int32_t trans;
+  int32_t taps;   int32_t cin;  int32_t rowmap;     /* PT_V_CONV / PT_V_WFLIP (cin = cout there) */
+  int32_t _pad;
+  int64_t n_out;  int64_t n_in;                     /* rows per batch item of the output / source */
+} pt_operand;
+
+enum pt_out_kind {
+  PT_OUT_T = 0,          /* store in `dtype`                                                      */
+  PT_OUT_F32 = 1,        /* store f32                                                             */
+  PT_OUT_F32_ATOMIC = 2  /* f32 atomicAdd (split-K wgrad into the flat grad buffer)               */
+};
+
+typedef struct pt_gemm_desc {
+  int64_t M, N, K;
+  pt_operand A, B;
+  void* C; int64_t ldc;
+  int32_t out_kind;
+  int32_t split_k;               /* >= 1; > 1 requires PT_OUT_F32_ATOMIC                          */
+  const float* bias;             /* [N] or NULL                                                   */
+  const float* row_bias;         /* [M / row_bias_rows][N] f32 (time-embedding add) or NULL       */
+  int64_t row_bias_rows;
+  const void* residual; int64_t ldr;   /* same dtype as activations, or NULL                      */
+  int32_t conv_wgrad_cin;        /* > 0: C index (m, n=tap*cin+ci) -> m*3*cin + ci*3 + tap (reference Conv1d weight layout) */
+  int32_t conv_wgrad_cin_store;  /* real Cin of the stored weight when cin is padded (conv_in)    */
+  float alpha;                   /* scales the accumulator before the epilogue adds               */
+} pt_gemm_desc;
+
+int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention (non-causal or causal, no padding mask unless kv_len given), flash-style, f32 softmax.
+ * q: [B*Nq][ldq] with head h at columns [h*D, (h+1)*D); k, v likewise over B*Nk rows.
+ * Replaces F.scaled_dot_product_attention in diffusers AttnProcessor2_0 (K5 in SURVEY 2.4)
+ * and its backward.  D in {32, 64, 128}.  lse: [B][H][Nq] f32.
+ * kv_len (int32 [B] or NULL): keys >= kv_len[b] are masked out (build-defined; reference = NULL).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pt_attn_desc {
+  int64_t B, H, Nq, Nk, D;
+  const void* q; int64_t ldq;
+  const void* k; int64_t ldk;
+  const void* v; int64_t ldv;
+  void* o; int64_t ldo;
+  float* lse;
+  float scale;
+  int32_t causal;
+  const int32_t* kv_len;
+  /* backward only */
+  const void* d_o; int64_t lddo;
+  float* delta;                  /* [B][H][Nq] f32 scratch: rowsum(dO * O) */
+  void* dq; int64_t lddq;
+  void* dk; int64_t lddk;
+  void* dv; int64_t lddv;
+} pt_attn_desc;
+
+int pt_attn_fwd(const pt_attn_desc* d, int dtype, pt_stream stream);
+int pt_attn_bwd(const pt_attn_desc* d, int dtype, pt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation / elementwise (HBM-bound).
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.LayerNorm(C, eps) over rows of x[M][C]  (diffusers BasicTransformerBlock.norm1/2/3). */
+int pt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int64_t M, int64_t C, float eps, int dtype, pt_stream stream);
+/* dx = LN'(dy) [+ dres];  dgamma/dbeta += (f32 atomics). */
+int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     const void* dres, void* dx, float* dgamma, float* dbeta,
+                     int64_t M, int64_t C, int dtype, pt_stream stream);
+
+/* nn.GroupNorm(G, C, eps) [+ SiLU] on token-major x = concat(x1[B][N][C1], x2[B][N][C2]) (x2 may be NULL)
+ * (tts/ldm/resnet.py:238-240,267-273; transformer_1d.py:251; unet_1d_condition.py:731-733). */
+int pt_groupnorm_stats(const void* x1, const void* x2, float* mean, float* rstd,
+                       int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, float eps, int dtype, pt_stream stream);
+int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, void* y, void* xcat /* raw concat copy or NULL */,
+                       int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int dtype, pt_stream stream);
+/* backward: ws = f32 [B][G][2] scratch (zeroed by the call).  dx1/dx2 = GN'(dy) [+ dres (concat layout)]. */
+int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
+                     float* dgamma, float* dbeta, float* ws,
+                     int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int accumulate_dx2,
+                     int dtype, pt_stream stream);
+
+/* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F]. */
+int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream);
+int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int dtype, pt_stream stream);
+
+/* SiLU on a flat f32/bf16 vector (time-embedding MLP, resnet.py:255-261). */
+int pt_silu_fwd(const void* x, void* y, int64_t n, int dtype, pt_stream stream);
+int pt_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, pt_stream stream);
+
+/* y = a + b (flat), y may alias a. */
+int pt_add(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream);
+/* y[r] = x[2r] + x[2r+1] over rows of C (dgrad of nearest x2 upsample). rows = output rows. */
+int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, int dtype, pt_stream stream);
+/* dbias[n] += sum_m dy[m][n]  (f32 atomics). */
+int pt_colsum(const void* dy, int64_t ld, float* dbias, int64_t M, int64_t N, int dtype, pt_stream stream);
+
+/* word_embedding(ids) + positional table (tts/models.py:112-115): out[b][s][:] = W[ids[b][s]][:] + pos[s][:]. */
+int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out,
+                     int64_t BS, int64_t S, int64_t d, int64_t vocab, int dtype, pt_stream stream);
+int pt_embedding_bwd(const int32_t* ids, const void* dout, float* dW, int64_t BS, int64_t d, int64_t vocab,
+                     int dtype, pt_stream stream);
+
+/* diffusers Timesteps(C, flip_sin_to_cos=True, shift): out[b] = [cos(t w_i) | sin(t w_i)] (unet_1d_condition.py:209,622). */
+int pt_timestep_embedding(const int64_t* t, void* out, int64_t B, int64_t C, int flip_sin_to_cos, float shift,
+                          int dtype, pt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-step ends (train.py:86-107,116-120).
+ * ---------------------------------------------------------------------------------------------- */
+/* x_t = sqrt(abar[t]) x0 + sqrt(1-abar[t]) eps;  in: (B, n_q, T) f32 channel-first;
+ * out: token-major [B*T][cpad] in `dtype` (channels >= n_q are zero). */
+int pt_add_noise(const float* x0, const float* noise, const int64_t* t, const float* alphas_cumprod,
+                 void* xt, int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream);
+/* token-major [B*T][cpad] -> (B, n_q, T) f32 (the `.sample` the reference returns) and back. */
+int pt_tokens_to_bct(const void* x, float* out, int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream);
+int pt_bct_to_tokens(const float* x, void* out, int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream);
+/* loss += mean((pred - noise)^2) (f32 atomic into *loss, caller zeroes) and dpred = 2 (pred-noise) / numel * gscale.
+ * pred token-major [B*T][cpad]; noise (B, n_q, T) f32; dpred token-major (pad channels zero). */
+int pt_mse_loss(const void* pred, const float* noise, float* loss, void* dpred, float gscale,
+                int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream);
+
+/* sum of squares of a flat f32 buffer into *out (f32 atomic; caller zeroes). */
+int pt_sumsq(const float* g, float* out, int64_t n, pt_stream stream);
+
+/* One fused AdamW step over a flat f32 master buffer (torch.optim.AdamW semantics, train.py:41-47,116-120):
+ * clip = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) read on device; p -= lr*wd*p; m,v update; p -= step.
+ * Also refreshes the activation-dtype weight shadow.  seg = table of n_seg tensors (pt_param_seg). */
+typedef struct pt_param_seg {
+  int64_t offset;        /* element offset in the flat master / grad / m / v buffers            */
+  int64_t numel;
+  int64_t shadow_offset; /* element offset in the shadow buffer                                 */
+  int32_t layout;        /* 0: copy; 1: Conv1d (Cout,Cin,3) -> shadow [Cout][3][cin_pad]          */
+  int32_t cin;           /* layout 1: Cin                                                        */
+  int32_t cin_pad;       /* layout 1: padded Cin of the shadow (>= cin, multiple of 8)           */
+  int32_t frozen;        /* 1: never updated (unused parameters: Transformer1DModel.proj_out)    */
+} pt_param_seg;
+
+int pt_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev,
+                  int64_t n_seg, int64_t n_total, const float* gnorm_sq, float max_norm,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  int dtype, pt_stream stream);
+/* shadow refresh only (after load_state_dict). */
+int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
+                   int dtype, pt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROMPT_TTS_HIP_H */

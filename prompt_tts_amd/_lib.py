@@ -1,0 +1,103 @@
+"""ctypes binding of the C-ABI library (include/prompt_tts_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol is absent,
+import fails loudly.  Nothing here touches ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
+
+PT_F32, PT_BF16 = 0, 1
+PT_V_PLAIN, PT_V_CONCAT, PT_V_CONV, PT_V_WFLIP = 0, 1, 2, 3
+PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD = 0, 1, 2, 3
+PT_OUT_T, PT_OUT_F32, PT_OUT_F32_ATOMIC = 0, 1, 2
+
+
+class pt_operand(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ld", C.c_int64), ("p2", C.c_void_p), ("ld2", C.c_int64),
+                ("c_split", C.c_int64), ("kind", C.c_int32), ("trans", C.c_int32), ("taps", C.c_int32),
+                ("cin", C.c_int32), ("rowmap", C.c_int32), ("_pad", C.c_int32),
+                ("n_out", C.c_int64), ("n_in", C.c_int64)]
+
+
+class pt_gemm_desc(C.Structure):
+    _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("A", pt_operand), ("B", pt_operand),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("out_kind", C.c_int32), ("split_k", C.c_int32),
+                ("bias", C.c_void_p), ("row_bias", C.c_void_p), ("row_bias_rows", C.c_int64),
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("conv_wgrad_cin", C.c_int32),
+                ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float)]
+
+
+class pt_attn_desc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("H", C.c_int64), ("Nq", C.c_int64), ("Nk", C.c_int64), ("D", C.c_int64),
+                ("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("ldk", C.c_int64),
+                ("v", C.c_void_p), ("ldv", C.c_int64), ("o", C.c_void_p), ("ldo", C.c_int64),
+                ("lse", C.c_void_p), ("scale", C.c_float), ("causal", C.c_int32), ("kv_len", C.c_void_p),
+                ("d_o", C.c_void_p), ("lddo", C.c_int64), ("delta", C.c_void_p),
+                ("dq", C.c_void_p), ("lddq", C.c_int64), ("dk", C.c_void_p), ("lddk", C.c_int64),
+                ("dv", C.c_void_p), ("lddv", C.c_int64)]
+
+
+class pt_param_seg(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("shadow_offset", C.c_int64),
+                ("layout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("frozen", C.c_int32)]
+
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> argtypes (all return int status unless noted); mirrors include/prompt_tts_hip.h one to one.
+SIGNATURES = {
+    "pt_gemm": [C.POINTER(pt_gemm_desc), _i32, _vp],
+    "pt_attn_fwd": [C.POINTER(pt_attn_desc), _i32, _vp],
+    "pt_attn_bwd": [C.POINTER(pt_attn_desc), _i32, _vp],
+    "pt_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
+    "pt_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_groupnorm_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp],
+    "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
+    "pt_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
+    "pt_geglu_fwd": [_vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_geglu_bwd": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_silu_fwd": [_vp, _vp, _i64, _i32, _vp],
+    "pt_silu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "pt_add": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "pt_pairsum_rows": [_vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
+    "pt_embedding_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_embedding_bwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pt_timestep_embedding": [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp],
+    "pt_add_noise": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_tokens_to_bct": [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_bct_to_tokens": [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_mse_loss": [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_sumsq": [_vp, _vp, _i64, _vp],
+    "pt_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
+                      _i32, _vp],
+    "pt_pack_shadow": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C prompt_tts_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.pt_abi_version.restype = C.c_int
+    lib.pt_status_string.restype = C.c_char_p
+    lib.pt_status_string.argtypes = [C.c_int]
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what}: {lib.pt_status_string(status).decode()} (status {status})")

@@ -1,0 +1,93 @@
+// Shared pieces of the flash-style attention kernels (forward, dK/dV, dQ).
+//
+// Orientation used everywhere ("the reduced index never leaves the lane group"):
+//   * the operand a wave OWNS for the whole kernel (its q rows, or its keys) sits in registers as MFMA
+//     B fragments (column = lane&15), loaded straight from HBM once;
+//   * the operand that streams (K/V tiles, or Q/dO tiles) is staged in LDS in ONE image per tensor that
+//     serves both row reads (reduction over d) and transposed reads (reduction over the tile's rows);
+//   * score tiles are therefore produced with the streamed index on accumulator ROWS and the owned index on
+//     the lane, so softmax statistics are per-lane scalars, and P / dS feed the next MFMA as B fragments
+//     directly from the accumulator registers (k order 16*(j>>2) + 4*(lane>>4) + (j&3), matched by the
+//     transposed LDS read of the other operand) -- P never touches LDS.
+#pragma once
+#include "mma.h"
+
+struct AttnParams {
+  int B, H, Nq, Nk;
+  const char* q; int64_t ldq;
+  const char* k; int64_t ldk;
+  const char* v; int64_t ldv;
+  char* o; int64_t ldo;
+  float* lse; float scale; int causal; const int32_t* kv_len;
+  const char* d_o; int64_t lddo; float* delta;
+  char* dq; int64_t lddq; char* dk; int64_t lddk; char* dv; int64_t lddv;
+};
+
+template <typename T, int D> struct AttnCfg {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int COLS = (D * (int)sizeof(T) >= 256) ? D : 256 / (int)sizeof(T);
+  using Img = TileT<T, COLS>;
+  static constexpr int ROWB = Img::ROWB;
+  static constexpr int KS = D / 32;     // reduction steps over the head dim
+  static constexpr int DT = D / 16;     // 16-wide tiles over the head dim
+  static constexpr int CPR = D / EPC;   // 16-byte chunks per data row
+};
+
+// row-read fragment (8 consecutive head-dim elements of image row r)
+template <int COLS>
+__device__ __forceinline__ void frag_load_n(Frag<bf16_t>& f, const char* base, int r, int k0) {
+  f.v = *reinterpret_cast<const bf16x8_t*>(base + TileT<bf16_t, COLS>::chunk_off(r, k0 >> 3));
+}
+template <int COLS>
+__device__ __forceinline__ void frag_load_n(Frag<float>& f, const char* base, int r, int k0) {
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(base + TileT<float, COLS>::chunk_off(r, k0 >> 2));
+  f32x4_t b = *reinterpret_cast<const f32x4_t*>(base + TileT<float, COLS>::chunk_off(r, (k0 >> 2) + 1));
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+
+// Stage ROWS x D elements (rows row0.., clipped to `limit` rows -> zero fill) HBM -> registers -> LDS image.
+template <typename T, int D, int ROWS> struct TileStage {
+  using Cfg = AttnCfg<T, D>;
+  static constexpr int NCHUNK = ROWS * Cfg::CPR;
+  static constexpr int PER = (NCHUNK + 255) / 256;
+  Vec16<T> r[PER];
+  __device__ __forceinline__ void load(const T* base, int64_t ld, int row0, int limit, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / Cfg::CPR, c = q - row * Cfg::CPR;
+      if (q < NCHUNK && row0 + row < limit) r[i] = load16(base + (int64_t)(row0 + row) * ld + c * Cfg::EPC);
+      else r[i] = zero16<T>();
+    }
+  }
+  __device__ __forceinline__ void store(char* img, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / Cfg::CPR, c = q - row * Cfg::CPR;
+      if (q < NCHUNK) Cfg::Img::store_chunk(img, row, c, r[i]);
+    }
+  }
+};
+
+// accumulator pair -> B fragment: elements 0..3 from tile lo, 4..7 from tile hi
+template <typename T>
+__device__ __forceinline__ void frag_from_acc(Frag<T>& f, const f32x4_t& lo, const f32x4_t& hi) {
+  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  frag_from_f32(f, x);
+}
+
+// store 4 consecutive elements of an output row
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  u32x2_t o;
+  o[0] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  o[1] = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  *reinterpret_cast<u32x2_t*>(p) = o;
+}
+
+#define PT_LOG2E 1.4426950408889634f

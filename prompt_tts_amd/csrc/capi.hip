@@ -1,0 +1,16 @@
+// ABI bookkeeping for the C library.
+#include "common.h"
+
+extern "C" int pt_abi_version(void) { return 1; }
+
+extern "C" const char* pt_status_string(int status) {
+  switch (status) {
+    case PT_OK: return "ok";
+    case PT_ERR_SHAPE: return "shape not supported by the kernel";
+    case PT_ERR_DTYPE: return "dtype must be PT_F32 or PT_BF16";
+    case PT_ERR_LAUNCH: return "HIP launch failed";
+    case PT_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+    case PT_ERR_ARG: return "invalid argument";
+    default: return "unknown status";
+  }
+}

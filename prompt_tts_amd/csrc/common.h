@@ -1,0 +1,106 @@
+// Device-side common definitions for the gfx950 kernels (wave64, MFMA 16x16, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/prompt_tts_hip.h"
+
+#define PT_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+struct bf16_t { uint16_t bits; };   // storage type for bf16 activations
+
+// ---- scalar conversions ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, h);
+}
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return bf16_bits_to_f32(x.bits); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { bf16_t r; r.bits = f32_to_bf16_bits(x); return r; }
+
+// ---- 16-byte vectors of activations: VEC<T> elements per 16 B ------------------------------------------
+template <typename T> struct vec_traits;
+template <> struct vec_traits<float> { static constexpr int N = 4; };
+template <> struct vec_traits<bf16_t> { static constexpr int N = 8; };
+
+template <typename T> struct Vec16 {
+  u32x4_t raw;
+  static constexpr int N = vec_traits<T>::N;
+  __device__ __forceinline__ float get(int i) const;
+  __device__ __forceinline__ void set(int i, float v);
+};
+template <> __device__ __forceinline__ float Vec16<float>::get(int i) const { return __uint_as_float(raw[i]); }
+template <> __device__ __forceinline__ void Vec16<float>::set(int i, float v) { raw[i] = __float_as_uint(v); }
+template <> __device__ __forceinline__ float Vec16<bf16_t>::get(int i) const {
+  uint32_t w = raw[i >> 1];
+  return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+template <> __device__ __forceinline__ void Vec16<bf16_t>::set(int i, float v) {
+  uint32_t b = f32_to_bf16_bits(v);
+  uint32_t w = raw[i >> 1];
+  raw[i >> 1] = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+}
+template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+  Vec16<T> v; v.raw = *reinterpret_cast<const u32x4_t*>(p); return v;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<u32x4_t*>(p) = v.raw;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() { Vec16<T> v; v.raw = (u32x4_t){0, 0, 0, 0}; return v; }
+
+// ---- reductions ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block sum for blockDim.x == NT (multiple of 64); every thread gets the result. scratch: NT/64 floats.
+template <int NT> __device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+  return r;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// host-side launch check
+#define PT_LAUNCH_CHECK()                                  \
+  do {                                                     \
+    if (hipPeekAtLastError() != hipSuccess) {              \
+      (void)hipGetLastError();                             \
+      return PT_ERR_LAUNCH;                                \
+    }                                                      \
+  } while (0)
+
+static inline bool pt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,361 @@
+// Elementwise / gather / reduction kernels of the denoiser training step.  All HBM-bound; 16-byte accesses,
+// grid capped at ~2048 blocks with grid-stride loops.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline unsigned grid_for(int64_t work_items) {
+  int64_t b = (work_items + NT - 1) / NT;
+  if (b < 1) b = 1;
+  return (unsigned)(b > 4096 ? 4096 : b);
+}
+
+// ---- GEGLU --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void geglu_fwd_kernel(const T* __restrict__ proj, T* __restrict__ out, int64_t M, int64_t F) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t cpr = F / EPC, total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t m = i / cpr, c = (i - m * cpr) * EPC;
+    Vec16<T> h = load16(proj + m * 2 * F + c), g = load16(proj + m * 2 * F + F + c), o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.set(e, h.get(e) * gelu_erf_f(g.get(e)));
+    store16(out + m * F + c, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void geglu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ proj,
+                                                       T* __restrict__ dproj, int64_t M, int64_t F) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t cpr = F / EPC, total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t m = i / cpr, c = (i - m * cpr) * EPC;
+    Vec16<T> h = load16(proj + m * 2 * F + c), g = load16(proj + m * 2 * F + F + c), d = load16(dout + m * F + c), dh, dg;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float gv = g.get(e), dv = d.get(e);
+      dh.set(e, dv * gelu_erf_f(gv));
+      dg.set(e, dv * h.get(e) * gelu_erf_grad_f(gv));
+    }
+    store16(dproj + m * 2 * F + c, dh);
+    store16(dproj + m * 2 * F + F + c, dg);
+  }
+}
+
+// ---- flat unary/binary ------------------------------------------------------------------------------------
+template <typename T, int OP>   // 0 silu fwd (a=x) ; 1 silu bwd (a=dy, b=x) ; 2 add
+__global__ __launch_bounds__(NT) void flat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t nv = n / EPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+    Vec16<T> va = load16(a + i * EPC), vb, o;
+    if (OP != 0) vb = load16(b + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float r;
+      if (OP == 0) r = silu_f(va.get(e));
+      else if (OP == 1) r = va.get(e) * silu_grad_f(vb.get(e));
+      else r = va.get(e) + vb.get(e);
+      o.set(e, r);
+    }
+    store16(y + i * EPC, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int64_t i = nv * EPC; i < n; ++i) {
+      const float x = to_f32<T>(a[i]);
+      float r;
+      if (OP == 0) r = silu_f(x);
+      else if (OP == 1) r = x * silu_grad_f(to_f32<T>(b[i]));
+      else r = x + to_f32<T>(b[i]);
+      y[i] = from_f32<T>(r);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void pairsum_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t C) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t cpr = C / EPC, total = rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t r = i / cpr, c = (i - r * cpr) * EPC;
+    Vec16<T> a = load16(x + (2 * r) * C + c), b = load16(x + (2 * r + 1) * C + c), o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.set(e, a.get(e) + b.get(e));
+    store16(y + r * C + c, o);
+  }
+}
+
+// dbias[n] += sum_m dy[m][n]: block = run of rows, thread = fixed column chunk
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ dbias,
+                                                    int64_t M, int N, int rows_per_block) {
+  constexpr int EPC = Vec16<T>::N;
+  const int CC = N / EPC;
+  const int CW = CC < NT ? CC : NT, RP = NT / CW;
+  const int cw = threadIdx.x % CW, rr = threadIdx.x / CW;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  extern __shared__ float sh[];
+  for (int i = threadIdx.x; i < N; i += NT) sh[i] = 0.f;
+  __syncthreads();
+  if (rr < RP) {
+    for (int c = cw; c < CC; c += CW) {
+      float acc[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+      for (int64_t r = r0 + rr; r < r1; r += RP) {
+        Vec16<T> v = load16(dy + r * ld + (int64_t)c * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += v.get(e);
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) atomicAdd(&sh[c * EPC + e], acc[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += NT) unsafeAtomicAdd(dbias + i, sh[i]);
+}
+
+// ---- embedding ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void embedding_fwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ W,
+                                                           const float* __restrict__ pos, T* __restrict__ out,
+                                                           int64_t BS, int64_t S, int64_t d, int64_t vocab) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t cpr = d / EPC, total = BS * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t r = i / cpr, c = (i - r * cpr) * EPC;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);      // ids are validated on the host; clamp keeps the read in bounds
+    const int64_t s = r % S;
+    Vec16<T> w = load16(W + id * d + c), o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.set(e, w.get(e) + pos[s * d + c + e]);
+    store16(out + r * d + c, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void embedding_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dout,
+                                                           float* __restrict__ dW, int64_t BS, int64_t d, int64_t vocab) {
+  const int64_t total = BS * d;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t r = i / d, c = i - r * d;
+    const int64_t id = ids[r];
+    if (id >= 0 && id < vocab) unsafeAtomicAdd(dW + id * d + c, to_f32<T>(dout[i]));
+  }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, T* __restrict__ out, int64_t B, int C, int flip, float shift) {
+  const int half = C / 2;
+  const int64_t total = B * half;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / half; const int k = (int)(i - b * half);
+    const float freq = expf(-9.210340371976184f * (float)k / ((float)half - shift));   // ln(10000)
+    const float ang = (float)t[b] * freq;
+    const float sn = sinf(ang), cs = cosf(ang);
+    T* o = out + b * C;
+    if (flip) { o[k] = from_f32<T>(cs); o[half + k] = from_f32<T>(sn); }
+    else      { o[k] = from_f32<T>(sn); o[half + k] = from_f32<T>(cs); }
+    if ((C & 1) && k == 0) o[C - 1] = from_f32<T>(0.f);
+  }
+}
+
+// ---- training-step ends -----------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                 const float* __restrict__ ac, T* __restrict__ xt, int64_t B, int nq, int64_t Tn, int cpad) {
+  const int64_t total = B * Tn * cpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad); const int64_t bt = i / cpad; const int64_t b = bt / Tn, n = bt - b * Tn;
+    float v = 0.f;
+    if (c < nq) {
+      const float a = ac[t[b]];
+      const int64_t src = (b * nq + c) * Tn + n;
+      v = sqrtf(a) * x0[src] + sqrtf(1.f - a) * noise[src];
+    }
+    xt[i] = from_f32<T>(v);
+  }
+}
+template <typename T>
+__global__ void tokens_to_bct_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t B, int nq, int64_t Tn, int cpad) {
+  const int64_t total = B * nq * Tn;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i % Tn; const int64_t bc = i / Tn; const int64_t b = bc / nq; const int c = (int)(bc - b * nq);
+    out[i] = to_f32<T>(x[(b * Tn + n) * cpad + c]);
+  }
+}
+template <typename T>
+__global__ void bct_to_tokens_kernel(const float* __restrict__ x, T* __restrict__ out, int64_t B, int nq, int64_t Tn, int cpad) {
+  const int64_t total = B * Tn * cpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad); const int64_t bt = i / cpad; const int64_t b = bt / Tn, n = bt - b * Tn;
+    out[i] = from_f32<T>(c < nq ? x[(b * nq + c) * Tn + n] : 0.f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void mse_kernel(const T* __restrict__ pred, const float* __restrict__ noise, float* __restrict__ loss,
+                                                 T* __restrict__ dpred, float gscale, int64_t B, int nq, int64_t Tn, int cpad) {
+  const int64_t total = B * Tn * cpad;
+  const float inv = 1.f / (float)(B * nq * Tn);
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % cpad); const int64_t bt = i / cpad; const int64_t b = bt / Tn, n = bt - b * Tn;
+    float g = 0.f;
+    if (c < nq) {
+      const float d = to_f32<T>(pred[i]) - noise[(b * nq + c) * Tn + n];
+      acc += d * d;
+      g = 2.f * d * inv * gscale;
+    }
+    if (dpred) dpred[i] = from_f32<T>(g);
+  }
+  __shared__ float sc[NT / 64];
+  acc = block_sum<NT>(acc, sc);
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, acc * inv);
+}
+
+__global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, int64_t n) {
+  const int64_t nv = n / 4;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(g + i * 4);
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = nv * 4; i < n; ++i) acc += g[i] * g[i];
+  __shared__ float sc[NT / 64];
+  acc = block_sum<NT>(acc, sc);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+}
+
+}  // namespace
+
+#define PT_DISPATCH(dtype, CALL_F32, CALL_BF16)          \
+  do {                                                   \
+    if ((dtype) == PT_F32) { CALL_F32; }                 \
+    else if ((dtype) == PT_BF16) { CALL_BF16; }          \
+    else return PT_ERR_DTYPE;                            \
+    PT_LAUNCH_CHECK();                                   \
+    return PT_OK;                                        \
+  } while (0)
+
+extern "C" int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream) {
+  if (M <= 0 || F <= 0 || F % 8 != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(proj) || !pt_aligned16(out)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((geglu_fwd_kernel<float>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)proj, (float*)out, M, F),
+              hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)proj, (bf16_t*)out, M, F));
+}
+extern "C" int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int dtype, pt_stream stream) {
+  if (M <= 0 || F <= 0 || F % 8 != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(proj) || !pt_aligned16(dout) || !pt_aligned16(dproj)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((geglu_bwd_kernel<float>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)dout, (const float*)proj, (float*)dproj, M, F),
+              hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)dout, (const bf16_t*)proj, (bf16_t*)dproj, M, F));
+}
+
+template <int OP> static int flat_launch(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream) {
+  if (n <= 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(a) || !pt_aligned16(y) || (b && !pt_aligned16(b))) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((flat_kernel<float, OP>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, (const float*)a, (const float*)b, (float*)y, n),
+              hipLaunchKernelGGL((flat_kernel<bf16_t, OP>), dim3(grid_for(n / 8 + 1)), dim3(NT), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n));
+}
+extern "C" int pt_silu_fwd(const void* x, void* y, int64_t n, int dtype, pt_stream stream) { return flat_launch<0>(x, nullptr, y, n, dtype, stream); }
+extern "C" int pt_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, pt_stream stream) {
+  if (!x) return PT_ERR_ARG;
+  return flat_launch<1>(dy, x, dx, n, dtype, stream);
+}
+extern "C" int pt_add(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream) {
+  if (!b) return PT_ERR_ARG;
+  return flat_launch<2>(a, b, y, n, dtype, stream);
+}
+
+extern "C" int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, int dtype, pt_stream stream) {
+  if (rows <= 0 || C <= 0 || C % 8 != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x) || !pt_aligned16(y)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((pairsum_kernel<float>), dim3(grid_for(rows * C / 4)), dim3(NT), 0, s, (const float*)x, (float*)y, rows, C),
+              hipLaunchKernelGGL((pairsum_kernel<bf16_t>), dim3(grid_for(rows * C / 8)), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
+}
+
+extern "C" int pt_colsum(const void* dy, int64_t ld, float* dbias, int64_t M, int64_t N, int dtype, pt_stream stream) {
+  if (M <= 0 || N <= 0 || N % 8 != 0 || N > 16384) return PT_ERR_SHAPE;
+  if (!pt_aligned16(dy) || (ld * (dtype == PT_F32 ? 4 : 2)) % 16 != 0) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = 128;
+  const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+  const size_t dyn = sizeof(float) * (size_t)N;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((colsum_kernel<float>), dim3(grid), dim3(NT), dyn, s, (const float*)dy, ld, dbias, M, (int)N, rpb),
+              hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(grid), dim3(NT), dyn, s, (const bf16_t*)dy, ld, dbias, M, (int)N, rpb));
+}
+
+extern "C" int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out, int64_t BS, int64_t S,
+                                int64_t d, int64_t vocab, int dtype, pt_stream stream) {
+  if (BS <= 0 || S <= 0 || d <= 0 || d % 8 != 0 || vocab <= 0 || BS % S != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(W) || !pt_aligned16(out)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((embedding_fwd_kernel<float>), dim3(grid_for(BS * d / 4)), dim3(NT), 0, s, ids, (const float*)W, pos, (float*)out, BS, S, d, vocab),
+              hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(grid_for(BS * d / 8)), dim3(NT), 0, s, ids, (const bf16_t*)W, pos, (bf16_t*)out, BS, S, d, vocab));
+}
+extern "C" int pt_embedding_bwd(const int32_t* ids, const void* dout, float* dW, int64_t BS, int64_t d, int64_t vocab,
+                                int dtype, pt_stream stream) {
+  if (BS <= 0 || d <= 0 || vocab <= 0) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((embedding_bwd_kernel<float>), dim3(grid_for(BS * d)), dim3(NT), 0, s, ids, (const float*)dout, dW, BS, d, vocab),
+              hipLaunchKernelGGL((embedding_bwd_kernel<bf16_t>), dim3(grid_for(BS * d)), dim3(NT), 0, s, ids, (const bf16_t*)dout, dW, BS, d, vocab));
+}
+
+extern "C" int pt_timestep_embedding(const int64_t* t, void* out, int64_t B, int64_t C, int flip, float shift, int dtype, pt_stream stream) {
+  if (B <= 0 || C < 2) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((timestep_embedding_kernel<float>), dim3(grid_for(B * C / 2)), dim3(NT), 0, s, t, (float*)out, B, (int)C, flip, shift),
+              hipLaunchKernelGGL((timestep_embedding_kernel<bf16_t>), dim3(grid_for(B * C / 2)), dim3(NT), 0, s, t, (bf16_t*)out, B, (int)C, flip, shift));
+}
+
+extern "C" int pt_add_noise(const float* x0, const float* noise, const int64_t* t, const float* ac, void* xt, int64_t B,
+                            int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream) {
+  if (B <= 0 || n_q <= 0 || T <= 0 || cpad < n_q) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((add_noise_kernel<float>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, x0, noise, t, ac, (float*)xt, B, (int)n_q, T, (int)cpad),
+              hipLaunchKernelGGL((add_noise_kernel<bf16_t>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, x0, noise, t, ac, (bf16_t*)xt, B, (int)n_q, T, (int)cpad));
+}
+extern "C" int pt_tokens_to_bct(const void* x, float* out, int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream) {
+  if (B <= 0 || n_q <= 0 || T <= 0 || cpad < n_q) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((tokens_to_bct_kernel<float>), dim3(grid_for(B * T * n_q)), dim3(NT), 0, s, (const float*)x, out, B, (int)n_q, T, (int)cpad),
+              hipLaunchKernelGGL((tokens_to_bct_kernel<bf16_t>), dim3(grid_for(B * T * n_q)), dim3(NT), 0, s, (const bf16_t*)x, out, B, (int)n_q, T, (int)cpad));
+}
+extern "C" int pt_bct_to_tokens(const float* x, void* out, int64_t B, int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream) {
+  if (B <= 0 || n_q <= 0 || T <= 0 || cpad < n_q) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((bct_to_tokens_kernel<float>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, x, (float*)out, B, (int)n_q, T, (int)cpad),
+              hipLaunchKernelGGL((bct_to_tokens_kernel<bf16_t>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, x, (bf16_t*)out, B, (int)n_q, T, (int)cpad));
+}
+extern "C" int pt_mse_loss(const void* pred, const float* noise, float* loss, void* dpred, float gscale, int64_t B,
+                           int64_t n_q, int64_t T, int64_t cpad, int dtype, pt_stream stream) {
+  if (B <= 0 || n_q <= 0 || T <= 0 || cpad < n_q) return PT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((mse_kernel<float>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, (const float*)pred, noise, loss, (float*)dpred, gscale, B, (int)n_q, T, (int)cpad),
+              hipLaunchKernelGGL((mse_kernel<bf16_t>), dim3(grid_for(B * T * cpad)), dim3(NT), 0, s, (const bf16_t*)pred, noise, loss, (bf16_t*)dpred, gscale, B, (int)n_q, T, (int)cpad));
+}
+extern "C" int pt_sumsq(const float* g, float* out, int64_t n, pt_stream stream) {
+  if (n <= 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(g)) return PT_ERR_ALIGN;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, g, out, n);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}

@@ -1,0 +1,520 @@
+// LayerNorm / GroupNorm(+SiLU) forward and backward on token-major activations.  HBM-bound: every kernel
+// streams its tensors once with 16-byte loads/stores; a thread keeps a FIXED column chunk while it walks rows,
+// so per-channel quantities (gamma/beta, scale/shift, dgamma/dbeta partials) live in registers.
+//   algorithmic bytes: LN fwd 2*M*C*s; LN bwd 3*M*C*s (+dres); GN stats M*C*s; GN apply 2*M*C*s;
+//   GN bwd 2*M*C*s (sums) + 3*M*C*s (apply)            (s = sizeof(T))
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, C <= 64*MAXC*EPC.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MAXC>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* __restrict__ y,
+                                                    float* __restrict__ mean, float* __restrict__ rstd,
+                                                    int64_t M, int C, float eps) {
+  constexpr int EPC = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* xr = x + row * C;
+  Vec16<T> v[MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int col = (lane + 64 * j) * EPC;
+    if (col < C) {
+      v[j] = load16(xr + col);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += v[j].get(e);
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int col = (lane + 64 * j) * EPC;
+    if (col < C) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { float d = v[j].get(e) - mu; ss += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  T* yr = y + row * C;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int col = (lane + 64 * j) * EPC;
+    if (col < C) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o.set(e, (v[j].get(e) - mu) * rs * gamma[col + e] + beta[col + e]);
+      store16(yr + col, o);
+    }
+  }
+}
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                    T* __restrict__ dx, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int64_t M, int C) {
+  constexpr int EPC = Vec16<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+  float gam[MAXC][EPC], dg[MAXC][EPC], db[MAXC][EPC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int col = (lane + 64 * j) * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { gam[j][e] = col < C ? gamma[col + e] : 0.f; dg[j][e] = 0.f; db[j][e] = 0.f; }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * (NT / 64) + wave; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    Vec16<T> vx[MAXC], vd[MAXC];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      const int col = (lane + 64 * j) * EPC;
+      if (col < C) {
+        vx[j] = load16(x + row * C + col);
+        vd[j] = load16(dy + row * C + col);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (vx[j].get(e) - mu) * rs, d = vd[j].get(e), dxh = d * gam[j][e];
+          c1 += dxh; c2 += dxh * xh;
+          dg[j][e] += d * xh; db[j][e] += d;
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)C; c2 = wave_sum(c2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      const int col = (lane + 64 * j) * EPC;
+      if (col < C) {
+        Vec16<T> o, r;
+        if (dres) r = load16(dres + row * C + col);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (vx[j].get(e) - mu) * rs;
+          float g = rs * (vd[j].get(e) * gam[j][e] - c1 - xh * c2);
+          if (dres) g += r.get(e);
+          o.set(e, g);
+        }
+        store16(dx + row * C + col, o);
+      }
+    }
+  }
+  // block-level reduce of the per-wave dgamma/dbeta partials through LDS, then one atomic per column per block
+  __shared__ float sh[2][64 * MAXC * EPC];
+  for (int w = 0; w < NT / 64; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int idx = (lane + 64 * j) * EPC + e;
+          if (w == 0) { sh[0][idx] = dg[j][e]; sh[1][idx] = db[j][e]; }
+          else { sh[0][idx] += dg[j][e]; sh[1][idx] += db[j][e]; }
+        }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < C; c += NT) {
+    unsafeAtomicAdd(dgamma + c, sh[0][c]);
+    unsafeAtomicAdd(dbeta + c, sh[1][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm on x = concat(x1[B][N][C1], x2[B][N][C2]) (token-major).  A block owns (batch b, a run of rows);
+// thread (cw, rr) owns column chunks cw + j*CW and rows rr, rr+RP, ...
+// ---------------------------------------------------------------------------------------------------
+struct GnGeom { int C1, C2, C, CC, CW, RP, J, G, cpg, N, rows_per_block; };
+
+template <typename T> __device__ __forceinline__ const T* gn_src(const T* x1, const T* x2, const GnGeom& g, int64_t row, int col) {
+  return col < g.C1 ? x1 + row * g.C1 + col : x2 + row * g.C2 + (col - g.C1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                      float* __restrict__ sum, float* __restrict__ sumsq, GnGeom g) {
+  constexpr int EPC = Vec16<T>::N;
+  const int b = blockIdx.y, r0 = blockIdx.x * g.rows_per_block, r1 = min(g.N, r0 + g.rows_per_block);
+  const int cw = threadIdx.x % g.CW, rr = threadIdx.x / g.CW;
+  float s[2][EPC], ss[2][EPC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[j][e] = 0.f; ss[j][e] = 0.f; }
+  if (rr < g.RP) {
+    for (int r = r0 + rr; r < r1; r += g.RP) {
+      const int64_t row = (int64_t)b * g.N + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = cw + j * g.CW;
+        if (j < g.J && c < g.CC) {
+          Vec16<T> v = load16(gn_src(x1, x2, g, row, c * EPC));
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { float f = v.get(e); s[j][e] += f; ss[j][e] += f * f; }
+        }
+      }
+    }
+  }
+  __shared__ float sh[2 * 256];
+  for (int i = threadIdx.x; i < 2 * g.G; i += NT) sh[i] = 0.f;
+  __syncthreads();
+  if (rr < g.RP) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cw + j * g.CW;
+      if (j < g.J && c < g.CC) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int grp = (c * EPC + e) / g.cpg;
+          atomicAdd(&sh[2 * grp], s[j][e]);
+          atomicAdd(&sh[2 * grp + 1], ss[j][e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.G; i += NT) {
+    unsafeAtomicAdd(sum + b * g.G + i, sh[2 * i]);
+    unsafeAtomicAdd(sumsq + b * g.G + i, sh[2 * i + 1]);
+  }
+}
+
+__global__ void gn_finalize_kernel(float* mean, float* rstd, int n, float cnt, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mu = mean[i] / cnt;
+  const float var = fmaxf(rstd[i] / cnt - mu * mu, 0.f);
+  mean[i] = mu;
+  rstd[i] = rsqrtf(var + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ y, T* __restrict__ xcat, GnGeom g, int silu) {
+  constexpr int EPC = Vec16<T>::N;
+  const int b = blockIdx.y, r0 = blockIdx.x * g.rows_per_block, r1 = min(g.N, r0 + g.rows_per_block);
+  const int cw = threadIdx.x % g.CW, rr = threadIdx.x / g.CW;
+  if (rr >= g.RP) return;
+  float sc[2][EPC], sf[2][EPC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sc[j][e] = 0.f; sf[j][e] = 0.f;
+      if (j < g.J && c < g.CC) {
+        const int col = c * EPC + e, grp = col / g.cpg;
+        const float mu = mean[b * g.G + grp], rs = rstd[b * g.G + grp];
+        sc[j][e] = rs * gamma[col];
+        sf[j][e] = beta[col] - mu * rs * gamma[col];
+      }
+    }
+  }
+  for (int r = r0 + rr; r < r1; r += g.RP) {
+    const int64_t row = (int64_t)b * g.N + r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cw + j * g.CW;
+      if (j < g.J && c < g.CC) {
+        Vec16<T> v = load16(gn_src(x1, x2, g, row, c * EPC)), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float z = v.get(e) * sc[j][e] + sf[j][e];
+          o.set(e, silu ? silu_f(z) : z);
+        }
+        store16(y + row * g.C + c * EPC, o);
+        if (xcat) store16(xcat + row * g.C + c * EPC, v);
+      }
+    }
+  }
+}
+
+// backward pass 1: per-column sums of dz and dz*xhat over this block's rows -> dgamma/dbeta (global, all b)
+// and per-(b,group) A = sum gamma*dz, Bq = sum gamma*dz*xhat into ws[b][G][2].
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ dy, const T* __restrict__ x1,
+                                                         const T* __restrict__ x2, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ ws, GnGeom g,
+                                                         int silu) {
+  constexpr int EPC = Vec16<T>::N;
+  const int b = blockIdx.y, r0 = blockIdx.x * g.rows_per_block, r1 = min(g.N, r0 + g.rows_per_block);
+  const int cw = threadIdx.x % g.CW, rr = threadIdx.x / g.CW;
+  float mu[2][EPC], rs[2][EPC], ga[2][EPC], be[2][EPC], sg[2][EPC], sb[2][EPC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      mu[j][e] = 0.f; rs[j][e] = 0.f; ga[j][e] = 0.f; be[j][e] = 0.f; sg[j][e] = 0.f; sb[j][e] = 0.f;
+      if (j < g.J && c < g.CC) {
+        const int col = c * EPC + e, grp = col / g.cpg;
+        mu[j][e] = mean[b * g.G + grp]; rs[j][e] = rstd[b * g.G + grp];
+        ga[j][e] = gamma[col]; be[j][e] = beta[col];
+      }
+    }
+  }
+  if (rr < g.RP) {
+    for (int r = r0 + rr; r < r1; r += g.RP) {
+      const int64_t row = (int64_t)b * g.N + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = cw + j * g.CW;
+        if (j < g.J && c < g.CC) {
+          Vec16<T> vx = load16(gn_src(x1, x2, g, row, c * EPC));
+          Vec16<T> vd = load16(dy + row * g.C + c * EPC);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float xh = (vx.get(e) - mu[j][e]) * rs[j][e];
+            float dz = vd.get(e);
+            if (silu) dz *= silu_grad_f(xh * ga[j][e] + be[j][e]);
+            sg[j][e] += dz * xh; sb[j][e] += dz;
+          }
+        }
+      }
+    }
+  }
+  // combine the RP row-lanes of each column through LDS
+  extern __shared__ float dyn[];                 // [2][C] column sums, then [2][G] group sums
+  float* colg = dyn; float* colb = dyn + g.C; float* grp2 = dyn + 2 * g.C;
+  for (int i = threadIdx.x; i < 2 * g.C + 2 * g.G; i += NT) dyn[i] = 0.f;
+  __syncthreads();
+  if (rr < g.RP) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cw + j * g.CW;
+      if (j < g.J && c < g.CC) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int col = c * EPC + e;
+          atomicAdd(&colg[col], sg[j][e]);
+          atomicAdd(&colb[col], sb[j][e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < g.C; col += NT) {
+    const float a = colg[col], bb = colb[col], gm = gamma[col];
+    unsafeAtomicAdd(dgamma + col, a);
+    unsafeAtomicAdd(dbeta + col, bb);
+    atomicAdd(&grp2[2 * (col / g.cpg)], gm * bb);        // A  = sum gamma*dz
+    atomicAdd(&grp2[2 * (col / g.cpg) + 1], gm * a);     // Bq = sum gamma*dz*xhat
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * g.G; i += NT) unsafeAtomicAdd(ws + (int64_t)b * 2 * g.G + i, grp2[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x1,
+                                                          const T* __restrict__ x2, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ws,
+                                                          const T* __restrict__ dres, T* __restrict__ dx1,
+                                                          T* __restrict__ dx2, GnGeom g, int silu, int acc_dx2) {
+  constexpr int EPC = Vec16<T>::N;
+  const int b = blockIdx.y, r0 = blockIdx.x * g.rows_per_block, r1 = min(g.N, r0 + g.rows_per_block);
+  const int cw = threadIdx.x % g.CW, rr = threadIdx.x / g.CW;
+  if (rr >= g.RP) return;
+  const float inv_cnt = 1.f / ((float)g.N * (float)g.cpg);
+  float mu[2][EPC], rs[2][EPC], ga[2][EPC], be[2][EPC], mA[2][EPC], mB[2][EPC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      mu[j][e] = rs[j][e] = ga[j][e] = be[j][e] = mA[j][e] = mB[j][e] = 0.f;
+      if (j < g.J && c < g.CC) {
+        const int col = c * EPC + e, grp = col / g.cpg;
+        mu[j][e] = mean[b * g.G + grp]; rs[j][e] = rstd[b * g.G + grp];
+        ga[j][e] = gamma[col]; be[j][e] = beta[col];
+        mA[j][e] = ws[((int64_t)b * g.G + grp) * 2] * inv_cnt;
+        mB[j][e] = ws[((int64_t)b * g.G + grp) * 2 + 1] * inv_cnt;
+      }
+    }
+  }
+  for (int r = r0 + rr; r < r1; r += g.RP) {
+    const int64_t row = (int64_t)b * g.N + r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cw + j * g.CW;
+      if (j < g.J && c < g.CC) {
+        const int col0 = c * EPC;
+        Vec16<T> vx = load16(gn_src(x1, x2, g, row, col0));
+        Vec16<T> vd = load16(dy + row * g.C + col0);
+        Vec16<T> vr, o;
+        if (dres) vr = load16(dres + row * g.C + col0);
+        T* dst = col0 < g.C1 ? dx1 + row * g.C1 + col0 : dx2 + row * g.C2 + (col0 - g.C1);
+        const bool accum = acc_dx2 && col0 >= g.C1;
+        Vec16<T> old;
+        if (accum) old = load16(dst);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (vx.get(e) - mu[j][e]) * rs[j][e];
+          float dz = vd.get(e);
+          if (silu) dz *= silu_grad_f(xh * ga[j][e] + be[j][e]);
+          float gr = rs[j][e] * (dz * ga[j][e] - mA[j][e] - xh * mB[j][e]);
+          if (dres) gr += vr.get(e);
+          if (accum) gr += old.get(e);
+          o.set(e, gr);
+        }
+        store16(dst, o);
+      }
+    }
+  }
+}
+
+template <typename T> int gn_geom(GnGeom& g, int64_t N, int64_t C1, int64_t C2, int64_t G) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t C = C1 + C2;
+  if (C <= 0 || G <= 0 || G > 256 || C % G != 0 || C1 % EPC != 0 || C2 % EPC != 0 || N <= 0) return PT_ERR_SHAPE;
+  g.C1 = (int)C1; g.C2 = (int)C2; g.C = (int)C; g.G = (int)G; g.cpg = (int)(C / G); g.N = (int)N;
+  g.CC = g.C / EPC;
+  g.CW = g.CC < NT ? g.CC : NT;
+  g.RP = NT / g.CW;
+  g.J = (g.CC + g.CW - 1) / g.CW;
+  if (g.J > 2) return PT_ERR_SHAPE;
+  g.rows_per_block = 64;
+  return PT_OK;
+}
+
+template <typename T>
+int ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t M,
+           int64_t C, float eps, hipStream_t s) {
+  constexpr int EPC = Vec16<T>::N;
+  const int chunks = (int)((C / EPC + 63) / 64);
+  dim3 grid((unsigned)((M + 3) / 4));
+#define LN_F(MC) hipLaunchKernelGGL((ln_fwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, (int)C, eps)
+  if (chunks <= 1) LN_F(1); else if (chunks <= 2) LN_F(2); else if (chunks <= 4) LN_F(4); else if (chunks <= 8) LN_F(8); else return PT_ERR_SHAPE;
+#undef LN_F
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+template <typename T>
+int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
+           void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, hipStream_t s) {
+  constexpr int EPC = Vec16<T>::N;
+  const int chunks = (int)((C / EPC + 63) / 64);
+  const int64_t want = (M + 3) / 4;
+  dim3 grid((unsigned)(want < 2048 ? want : 2048));
+#define LN_B(MC) hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, M, (int)C)
+  if (chunks <= 1) LN_B(1); else if (chunks <= 2) LN_B(2); else if (chunks <= 4) LN_B(4); else return PT_ERR_SHAPE;
+#undef LN_B
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int64_t M, int64_t C, float eps, int dtype, pt_stream stream) {
+  if (M <= 0 || C <= 0 || C % 8 != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x) || !pt_aligned16(y)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32) return ln_fwd<float>(x, gamma, beta, y, mean, rstd, M, C, eps, s);
+  if (dtype == PT_BF16) return ln_fwd<bf16_t>(x, gamma, beta, y, mean, rstd, M, C, eps, s);
+  return PT_ERR_DTYPE;
+}
+
+extern "C" int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int dtype,
+                                pt_stream stream) {
+  if (M <= 0 || C <= 0 || C % 8 != 0) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x) || !pt_aligned16(dy) || !pt_aligned16(dx) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32) return ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, s);
+  if (dtype == PT_BF16) return ln_bwd<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, s);
+  return PT_ERR_DTYPE;
+}
+
+template <typename T>
+static int gn_stats_t(const void* x1, const void* x2, float* mean, float* rstd, int64_t B, int64_t N, int64_t C1,
+                      int64_t C2, int64_t G, float eps, hipStream_t s) {
+  GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
+  if (hipMemsetAsync(mean, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
+  if (hipMemsetAsync(rstd, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
+  dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
+  hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(NT), 0, s, (const T*)x1, (const T*)x2, mean, rstd, g);
+  const int n = (int)(B * G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mean, rstd, n, (float)N * (float)g.cpg, eps);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_groupnorm_stats(const void* x1, const void* x2, float* mean, float* rstd, int64_t B, int64_t N,
+                                  int64_t C1, int64_t C2, int64_t G, float eps, int dtype, pt_stream stream) {
+  if (B <= 0 || (C2 > 0 && !x2)) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x1) || (x2 && !pt_aligned16(x2))) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32) return gn_stats_t<float>(x1, x2, mean, rstd, B, N, C1, C2, G, eps, s);
+  if (dtype == PT_BF16) return gn_stats_t<bf16_t>(x1, x2, mean, rstd, B, N, C1, C2, G, eps, s);
+  return PT_ERR_DTYPE;
+}
+
+template <typename T>
+static int gn_apply_t(const void* x1, const void* x2, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, void* y, void* xcat, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G,
+                      int silu, hipStream_t s) {
+  GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
+  dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
+  hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(NT), 0, s, (const T*)x1, (const T*)x2, mean, rstd, gamma, beta,
+                     (T*)y, (T*)xcat, g, silu);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, void* y, void* xcat, int64_t B, int64_t N,
+                                  int64_t C1, int64_t C2, int64_t G, int silu, int dtype, pt_stream stream) {
+  if (B <= 0 || (C2 > 0 && !x2)) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x1) || (x2 && !pt_aligned16(x2)) || !pt_aligned16(y) || (xcat && !pt_aligned16(xcat))) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32) return gn_apply_t<float>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, s);
+  if (dtype == PT_BF16) return gn_apply_t<bf16_t>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, s);
+  return PT_ERR_DTYPE;
+}
+
+template <typename T>
+static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2, float* dgamma,
+                    float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu,
+                    int acc_dx2, hipStream_t s) {
+  GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * B * G * 2, s) != hipSuccess) return PT_ERR_LAUNCH;
+  dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
+  const size_t dyn = sizeof(float) * (2 * (size_t)g.C + 2 * (size_t)g.G);
+  hipLaunchKernelGGL((gn_bwd_sums_kernel<T>), grid, dim3(NT), dyn, s, (const T*)dy, (const T*)x1, (const T*)x2, mean,
+                     rstd, gamma, beta, dgamma, dbeta, ws, g, silu);
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x1, (const T*)x2, mean,
+                     rstd, gamma, beta, ws, (const T*)dres, (T*)dx1, (T*)dx2, g, silu, acc_dx2);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
+                                float* dgamma, float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2,
+                                int64_t G, int silu, int accumulate_dx2, int dtype, pt_stream stream) {
+  if (B <= 0 || (C2 > 0 && (!x2 || !dx2))) return PT_ERR_SHAPE;
+  if (!pt_aligned16(dy) || !pt_aligned16(x1) || !pt_aligned16(dx1) || (x2 && !pt_aligned16(x2)) ||
+      (dx2 && !pt_aligned16(dx2)) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, s);
+  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, s);
+  return PT_ERR_DTYPE;
+}

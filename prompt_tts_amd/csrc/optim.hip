@@ -1,0 +1,100 @@
+// Fused AdamW over ONE flat f32 master buffer (all parameters of the model), with global-norm clipping read
+// from device memory (no host sync) and the activation-dtype weight-shadow refresh fused in.
+// HBM-bound: 16 B/param read (p, g, m, v) + 12 B/param written (p, m, v) + sizeof(T) shadow write.
+// Semantics = torch.optim.AdamW (decoupled weight decay, bias-corrected), train.py:41-47,116-120.
+#include "common.h"
+
+namespace {
+constexpr int NT = 256;
+constexpr int CHUNK = 4096;   // elements of the flat buffer per block-iteration
+
+__device__ __forceinline__ int find_seg(const pt_param_seg* seg, int n_seg, int64_t pos) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].offset <= pos) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename T>
+__device__ __forceinline__ void shadow_store(T* shadow, const pt_param_seg& sg, int64_t local, float val) {
+  if (sg.layout == 0) {
+    shadow[sg.shadow_offset + local] = from_f32<T>(val);
+  } else {  // Conv1d weight (Cout, Cin, 3) -> [Cout][3][cin_pad]
+    const int64_t per_co = (int64_t)sg.cin * 3;
+    const int64_t co = local / per_co; const int rem = (int)(local - co * per_co);
+    const int ci = rem / 3, tap = rem - ci * 3;
+    shadow[sg.shadow_offset + (co * 3 + tap) * sg.cin_pad + ci] = from_f32<T>(val);
+  }
+}
+
+template <typename T, bool UPDATE>
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, T* __restrict__ shadow,
+                                                   const pt_param_seg* __restrict__ seg, int n_seg, int64_t n_total,
+                                                   const float* __restrict__ gnorm_sq, float max_norm, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2) {
+  float clip = 1.f;
+  if (UPDATE && gnorm_sq) {
+    const float nrm = sqrtf(*gnorm_sq);
+    clip = fminf(1.f, max_norm / (nrm + 1e-6f));       // torch.nn.utils.clip_grad_norm_
+  }
+  for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < n_total; base += (int64_t)gridDim.x * CHUNK) {
+    for (int k = threadIdx.x; k < CHUNK; k += NT) {
+      const int64_t i = base + k;
+      if (i >= n_total) break;
+      const int si = find_seg(seg, n_seg, i);
+      const pt_param_seg sg = seg[si];
+      const int64_t local = i - sg.offset;
+      if (local >= sg.numel) continue;                 // alignment padding between tensors
+      float pv = p[i];
+      if (UPDATE && !sg.frozen) {
+        const float gv = g[i] * clip;
+        pv *= 1.f - lr * wd;
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv; v[i] = vv;
+        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+        pv -= (lr / bc1) * (mv / denom);
+        p[i] = pv;
+      }
+      shadow_store<T>(shadow, sg, local, pv);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pt_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev,
+                             int64_t n_seg, int64_t n_total, const float* gnorm_sq, float max_norm, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, int dtype, pt_stream stream) {
+  if (n_seg <= 0 || n_total <= 0 || step <= 0) return PT_ERR_SHAPE;
+  if (!p || !g || !m || !v || !shadow || !seg_dev) return PT_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  int64_t blocks = (n_total + CHUNK - 1) / CHUNK;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32)
+    hipLaunchKernelGGL((adamw_kernel<float, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p, g, m, v, (float*)shadow, seg_dev, (int)n_seg, n_total, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+  else if (dtype == PT_BF16)
+    hipLaunchKernelGGL((adamw_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p, g, m, v, (bf16_t*)shadow, seg_dev, (int)n_seg, n_total, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+  else return PT_ERR_DTYPE;
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
+                              int dtype, pt_stream stream) {
+  if (n_seg <= 0 || n_total <= 0) return PT_ERR_SHAPE;
+  if (!p || !shadow || !seg_dev) return PT_ERR_ARG;
+  int64_t blocks = (n_total + CHUNK - 1) / CHUNK;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PT_F32)
+    hipLaunchKernelGGL((adamw_kernel<float, false>), dim3((unsigned)blocks), dim3(NT), 0, s, const_cast<float*>(p), nullptr, nullptr, nullptr, (float*)shadow, seg_dev, (int)n_seg, n_total, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
+  else if (dtype == PT_BF16)
+    hipLaunchKernelGGL((adamw_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(NT), 0, s, const_cast<float*>(p), nullptr, nullptr, nullptr, (bf16_t*)shadow, seg_dev, (int)n_seg, n_total, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
+  else return PT_ERR_DTYPE;
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}

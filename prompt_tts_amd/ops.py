@@ -1,0 +1,226 @@
+"""Thin host wrappers: torch device tensors in, C-ABI calls out (on torch's current HIP stream).
+
+PyTorch is plumbing here (device memory + streams); every device op below is a hand-written HIP
+kernel in prompt_tts_amd/csrc reached through include/prompt_tts_hip.h.  No CPU fallbacks.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+
+_DT = {torch.float32: L.PT_F32, torch.bfloat16: L.PT_BF16}
+
+
+def pt_dtype(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"activation dtype must be float32 or bfloat16, got {t.dtype}") from None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("prompt_tts_amd ops need tensors on the GPU; there is no CPU path")
+
+
+# ---- operand builders ---------------------------------------------------------------------------------
+
+def plain(t, ld=None, trans=False):
+    """2-D row-major view [rows][cols] with leading dimension ld (elements)."""
+    o = L.pt_operand()
+    o.p = t.data_ptr(); o.ld = ld if ld is not None else t.stride(0)
+    o.kind = L.PT_V_PLAIN; o.trans = int(trans)
+    return o
+
+
+def concat(t1, t2, trans=False):
+    o = L.pt_operand()
+    o.p = t1.data_ptr(); o.ld = t1.stride(0); o.p2 = t2.data_ptr(); o.ld2 = t2.stride(0)
+    o.c_split = t1.shape[1]; o.kind = L.PT_V_CONCAT; o.trans = int(trans)
+    return o
+
+
+def conv(t, cin, n_out, n_in, rowmap=L.PT_MAP_S1, taps=3, trans=False):
+    o = L.pt_operand()
+    o.p = t.data_ptr(); o.ld = t.stride(0); o.kind = L.PT_V_CONV; o.trans = int(trans)
+    o.taps = taps; o.cin = cin; o.rowmap = rowmap; o.n_out = n_out; o.n_in = n_in
+    return o
+
+
+def wflip(w3, cout, cin_pad, trans=True):
+    """conv weight shadow [Cout][3][cin_pad] read as V[tap*Cout + co][ci] = W[co][2-tap][ci]."""
+    o = L.pt_operand()
+    o.p = w3.data_ptr(); o.ld = cin_pad; o.kind = L.PT_V_WFLIP; o.trans = int(trans); o.cin = cout; o.taps = 3
+    return o
+
+
+def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bias=None, row_bias=None,
+         row_bias_rows=0, residual=None, ldr=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0):
+    d = L.pt_gemm_desc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.B = A, B
+    d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
+    d.out_kind = out_kind; d.split_k = split_k
+    d.bias = _p(bias); d.row_bias = _p(row_bias); d.row_bias_rows = row_bias_rows
+    d.residual = _p(residual); d.ldr = ldr
+    d.conv_wgrad_cin = conv_wgrad_cin; d.conv_wgrad_cin_store = conv_wgrad_cin_store
+    d.alpha = alpha
+    check(lib.pt_gemm(C.byref(d), dtype, _stream()), "pt_gemm")
+
+
+def attn_desc(q, k, v, o, lse, B, H, Nq, Nk, D, scale, causal=False, kv_len=None):
+    d = L.pt_attn_desc()
+    d.B, d.H, d.Nq, d.Nk, d.D = B, H, Nq, Nk, D
+    d.q, d.ldq = q.data_ptr(), q.stride(0)
+    d.k, d.ldk = k.data_ptr(), k.stride(0)
+    d.v, d.ldv = v.data_ptr(), v.stride(0)
+    d.o, d.ldo = o.data_ptr(), o.stride(0)
+    d.lse = lse.data_ptr(); d.scale = scale; d.causal = int(causal); d.kv_len = _p(kv_len)
+    return d
+
+
+def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, D, scale, causal=False, kv_len=None):
+    """q: [B*Nq, >=H*D] rows (column slices allowed), k/v: [B*Nk, ...]; o like q; lse f32 [B,H,Nq]."""
+    _dev(q, k, v, o, lse)
+    d = attn_desc(q, k, v, o, lse, B, H, Nq, Nk, D, scale, causal, kv_len)
+    check(lib.pt_attn_fwd(C.byref(d), pt_dtype(q), _stream()), "pt_attn_fwd")
+
+
+def attn_bwd(q, k, v, o, lse, do, delta, dq, dk, dv, B, H, Nq, Nk, D, scale, causal=False, kv_len=None):
+    _dev(q, k, v, o, lse, do, delta, dq, dk, dv)
+    d = attn_desc(q, k, v, o, lse, B, H, Nq, Nk, D, scale, causal, kv_len)
+    d.d_o, d.lddo = do.data_ptr(), do.stride(0)
+    d.delta = delta.data_ptr()
+    d.dq, d.lddq = dq.data_ptr(), dq.stride(0)
+    d.dk, d.lddk = dk.data_ptr(), dk.stride(0)
+    d.dv, d.lddv = dv.data_ptr(), dv.stride(0)
+    check(lib.pt_attn_bwd(C.byref(d), pt_dtype(q), _stream()), "pt_attn_bwd")
+
+
+# ---- norms / elementwise ---------------------------------------------------------------------------------
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
+    M, Cc = x.shape
+    check(lib.pt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, pt_dtype(x),
+                               _stream()), "pt_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta):
+    M, Cc = x.shape
+    check(lib.pt_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
+                               _p(dbeta), M, Cc, pt_dtype(x), _stream()), "pt_layernorm_bwd")
+
+
+def groupnorm_stats(x1, x2, mean, rstd, B, N, G, eps):
+    C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
+    check(lib.pt_groupnorm_stats(_p(x1), _p(x2), _p(mean), _p(rstd), B, N, C1, C2, G, eps, pt_dtype(x1), _stream()),
+          "pt_groupnorm_stats")
+
+
+def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu):
+    C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
+    check(lib.pt_groupnorm_apply(_p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _p(xcat),
+                                 B, N, C1, C2, G, int(silu), pt_dtype(x1), _stream()), "pt_groupnorm_apply")
+
+
+def groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, G, silu,
+                  accumulate_dx2=False):
+    C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
+    check(lib.pt_groupnorm_bwd(_p(dy), _p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dres), _p(dx1),
+                               _p(dx2), _p(dgamma), _p(dbeta), _p(ws), B, N, C1, C2, G, int(silu),
+                               int(accumulate_dx2), pt_dtype(x1), _stream()), "pt_groupnorm_bwd")
+
+
+def geglu_fwd(proj, out):
+    M, F2 = proj.shape
+    check(lib.pt_geglu_fwd(_p(proj), _p(out), M, F2 // 2, pt_dtype(proj), _stream()), "pt_geglu_fwd")
+
+
+def geglu_bwd(dout, proj, dproj):
+    M, F2 = proj.shape
+    check(lib.pt_geglu_bwd(_p(dout), _p(proj), _p(dproj), M, F2 // 2, pt_dtype(proj), _stream()), "pt_geglu_bwd")
+
+
+def silu_fwd(x, y):
+    check(lib.pt_silu_fwd(_p(x), _p(y), x.numel(), pt_dtype(x), _stream()), "pt_silu_fwd")
+
+
+def silu_bwd(dy, x, dx):
+    check(lib.pt_silu_bwd(_p(dy), _p(x), _p(dx), x.numel(), pt_dtype(x), _stream()), "pt_silu_bwd")
+
+
+def add(a, b, y):
+    check(lib.pt_add(_p(a), _p(b), _p(y), a.numel(), pt_dtype(a), _stream()), "pt_add")
+
+
+def pairsum_rows(x, y):
+    rows, Cc = y.shape
+    check(lib.pt_pairsum_rows(_p(x), _p(y), rows, Cc, pt_dtype(x), _stream()), "pt_pairsum_rows")
+
+
+def colsum(dy, dbias, M=None, N=None):
+    M = dy.shape[0] if M is None else M
+    N = dy.shape[1] if N is None else N
+    check(lib.pt_colsum(_p(dy), dy.stride(0), _p(dbias), M, N, pt_dtype(dy), _stream()), "pt_colsum")
+
+
+def embedding_fwd(ids, W, pos, out, S):
+    BS, d = out.shape
+    check(lib.pt_embedding_fwd(_p(ids), _p(W), _p(pos), _p(out), BS, S, d, W.shape[0], pt_dtype(out), _stream()),
+          "pt_embedding_fwd")
+
+
+def embedding_bwd(ids, dout, dW):
+    BS, d = dout.shape
+    check(lib.pt_embedding_bwd(_p(ids), _p(dout), _p(dW), BS, d, dW.shape[0], pt_dtype(dout), _stream()),
+          "pt_embedding_bwd")
+
+
+def timestep_embedding(t, out, flip_sin_to_cos=True, shift=0.0):
+    B, Cc = out.shape
+    check(lib.pt_timestep_embedding(_p(t), _p(out), B, Cc, int(flip_sin_to_cos), shift, pt_dtype(out), _stream()),
+          "pt_timestep_embedding")
+
+
+def add_noise(x0, noise, t, alphas_cumprod, xt, n_q, T, cpad):
+    B = x0.shape[0]
+    check(lib.pt_add_noise(_p(x0), _p(noise), _p(t), _p(alphas_cumprod), _p(xt), B, n_q, T, cpad, pt_dtype(xt),
+                           _stream()), "pt_add_noise")
+
+
+def tokens_to_bct(x, out, B, n_q, T, cpad):
+    check(lib.pt_tokens_to_bct(_p(x), _p(out), B, n_q, T, cpad, pt_dtype(x), _stream()), "pt_tokens_to_bct")
+
+
+def bct_to_tokens(x, out, B, n_q, T, cpad):
+    check(lib.pt_bct_to_tokens(_p(x), _p(out), B, n_q, T, cpad, pt_dtype(out), _stream()), "pt_bct_to_tokens")
+
+
+def mse_loss(pred, noise, loss, dpred, gscale, B, n_q, T, cpad):
+    check(lib.pt_mse_loss(_p(pred), _p(noise), _p(loss), _p(dpred), gscale, B, n_q, T, cpad, pt_dtype(pred),
+                          _stream()), "pt_mse_loss")
+
+
+def sumsq(g, out):
+    check(lib.pt_sumsq(_p(g), _p(out), g.numel(), _stream()), "pt_sumsq")
+
+
+def adamw_step(p, g, m, v, shadow, seg_dev, n_seg, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, step):
+    check(lib.pt_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(seg_dev), n_seg, p.numel(), _p(gnorm_sq),
+                            max_norm, lr, beta1, beta2, eps, wd, step, pt_dtype(shadow), _stream()), "pt_adamw_step")
+
+
+def pack_shadow(p, shadow, seg_dev, n_seg):
+    check(lib.pt_pack_shadow(_p(p), _p(shadow), _p(seg_dev), n_seg, p.numel(), pt_dtype(shadow), _stream()),
+          "pt_pack_shadow")
