@@ -28,6 +28,7 @@ struct GemmParams {
   int out_kind, split_k;
   const float* bias; const float* row_bias; int64_t row_bias_rows;
   const char* residual; int64_t ldr;
+  const char* residual2; int64_t ldr2;
   int conv_wgrad_cin, conv_wgrad_cin_store;
   float alpha;
   int tiles_m, tiles_n;
@@ -211,6 +212,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
         }
+        if (p.residual2) {
+          const T* rp = reinterpret_cast<const T*>(p.residual2) + m * p.ldr2 + n;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+        }
         if (p.out_kind == PT_OUT_F32) {
           *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
         } else {
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           if (p.bias) x += p.bias[n + r];
           if (rbias) x += rbias[n + r];
           if (p.residual) x += to_f32<T>(reinterpret_cast<const T*>(p.residual)[m * p.ldr + n + r]);
+          if (p.residual2) x += to_f32<T>(reinterpret_cast<const T*>(p.residual2)[m * p.ldr2 + n + r]);
           if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C)[m * p.ldc + n + r] = x;
           else reinterpret_cast<T*>(p.C)[m * p.ldc + n + r] = from_f32<T>(x);
         }
@@ -296,7 +303,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   if (!d->C) return PT_ERR_ARG;
   if (d->out_kind < PT_OUT_T || d->out_kind > PT_OUT_F32_ATOMIC) return PT_ERR_ARG;
   if (d->split_k < 1 || (d->split_k > 1 && d->out_kind != PT_OUT_F32_ATOMIC)) return PT_ERR_ARG;
-  if (d->out_kind == PT_OUT_F32_ATOMIC && (d->bias || d->row_bias || d->residual)) return PT_ERR_ARG;
+  if (d->out_kind == PT_OUT_F32_ATOMIC && (d->bias || d->row_bias || d->residual || d->residual2)) return PT_ERR_ARG;
   if (d->out_kind != PT_OUT_F32_ATOMIC) {
     const int oes = d->out_kind == PT_OUT_F32 ? 4 : es;
     if ((reinterpret_cast<uintptr_t>(d->C) & 15u) || (d->ldc * oes) % (4 * oes) != 0) return PT_ERR_ALIGN;
@@ -313,6 +320,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.out_kind = d->out_kind; p.split_k = d->split_k;
   p.bias = d->bias; p.row_bias = d->row_bias; p.row_bias_rows = d->row_bias_rows;
   p.residual = reinterpret_cast<const char*>(d->residual); p.ldr = d->ldr;
+  p.residual2 = reinterpret_cast<const char*>(d->residual2); p.ldr2 = d->ldr2;
   p.conv_wgrad_cin = d->conv_wgrad_cin;
   p.conv_wgrad_cin_store = d->conv_wgrad_cin_store > 0 ? d->conv_wgrad_cin_store : d->conv_wgrad_cin;
   p.alpha = d->alpha;

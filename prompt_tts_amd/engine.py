@@ -1,0 +1,263 @@
+"""Host-side execution engine: flat parameter store + layer forward/backward built from the C-ABI kernels.
+
+Layout decisions (MI355X-first):
+  * every activation is token-major (B*N, C) in the activation dtype (bf16 for speed, f32 for parity);
+    there is no (B,C,N)<->(B,N,C) flip and no channel-concat copy anywhere in the model;
+  * ALL parameters live in one flat f32 master buffer (nn.Parameters are views into it, so state_dict
+    keys/shapes are the reference's), with flat f32 grad / Adam m / v buffers beside it and one
+    activation-dtype "shadow" copy in kernel layout (Conv1d k=3 weights as [Cout][3][Cin]);
+  * weight gradients are written by the wgrad kernels straight into the flat grad buffer (f32 atomics,
+    split-K) -- one fused AdamW launch, one norm reduction and a handful of large all-reduce buckets.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+ALIGN = 64  # elements; keeps every tensor 16-byte aligned in both f32 and bf16 buffers
+
+
+def _round_up(x, a):
+    return (x + a - 1) // a * a
+
+
+class ParamStore:
+    """Flat storage for every parameter of `module` on `device`; `dtype` is the activation/shadow dtype."""
+
+    def __init__(self, module, device, dtype):
+        self.device, self.dtype, self.pt = device, dtype, ops._DT[dtype]
+        self.names, self.params, self.info = [], [], {}
+        off = soff = 0
+        segs = []
+        for name, p in module.named_parameters():
+            n = p.numel()
+            is_conv3 = p.dim() == 3 and p.shape[2] == 3
+            frozen = name.endswith("proj_out.weight") or name.endswith("proj_out.bias")
+            if is_conv3:
+                cout, cin = p.shape[0], p.shape[1]
+                cin_pad, cout_pad = _round_up(cin, 8), _round_up(cout, 8)
+                sn = cout_pad * 3 * cin_pad
+                seg = (off, n, soff, 1, cin, cin_pad, int(frozen))
+                sshape = (cout_pad, 3 * cin_pad)
+            else:
+                sn = n
+                cin = cin_pad = 0
+                seg = (off, n, soff, 0, 0, 0, int(frozen))
+                sshape = (p.shape[0], n // p.shape[0]) if p.dim() >= 2 else (n,)
+            self.names.append(name); self.params.append(p)
+            self.info[id(p)] = dict(off=off, n=n, soff=soff, sn=sn, sshape=sshape, frozen=frozen, name=name)
+            segs.append(seg)
+            off += _round_up(n, ALIGN); soff += _round_up(sn, ALIGN)
+        self.n_total, self.n_shadow, self.n_seg = off, soff, len(segs)
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(soff, dtype=dtype, device=device)
+        self.adam_m = self.adam_v = None
+        self.step_count = 0
+        arr = (L.pt_param_seg * len(segs))()
+        for i, s in enumerate(segs):
+            arr[i].offset, arr[i].numel, arr[i].shadow_offset, arr[i].layout, arr[i].cin, arr[i].cin_pad, arr[i].frozen = s
+        raw = bytes(arr)
+        self.seg_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        with torch.no_grad():
+            for p in self.params:
+                i = self.info[id(p)]
+                view = self.flat_p[i["off"]:i["off"] + i["n"]].view(p.shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = None
+        self.attach_grads()
+        self.refresh_shadow()
+
+    # -- views -------------------------------------------------------------------------------------------
+    def w(self, p):
+        i = self.info[id(p)]
+        return self.shadow[i["soff"]:i["soff"] + i["sn"]].view(i["sshape"])
+
+    def g(self, p):
+        i = self.info[id(p)]
+        return self.flat_g[i["off"]:i["off"] + i["n"]].view(p.shape)
+
+    def f(self, p):
+        return p.data
+
+    def fused(self, ps):
+        """(shadow2d, grad2d) over adjacent 2-D parameters stacked along rows (e.g. to_q|to_k|to_v), or None."""
+        infos = [self.info[id(p)] for p in ps]
+        cols = ps[0].shape[1]
+        for a, b, pa in zip(infos[:-1], infos[1:], ps[:-1]):
+            if a["off"] + a["n"] != b["off"] or a["soff"] + a["sn"] != b["soff"] or pa.shape[1] != cols:
+                return None
+        rows = sum(p.shape[0] for p in ps)
+        i0 = infos[0]
+        return (self.shadow[i0["soff"]:i0["soff"] + rows * cols].view(rows, cols),
+                self.flat_g[i0["off"]:i0["off"] + rows * cols].view(rows, cols))
+
+    def span(self, ps):
+        """[lo, hi) element range of the flat buffers covering parameters ps (registration-contiguous)."""
+        infos = [self.info[id(p)] for p in ps]
+        return min(i["off"] for i in infos), max(i["off"] + _round_up(i["n"], ALIGN) for i in infos)
+
+    # -- maintenance ---------------------------------------------------------------------------------------
+    def attach_grads(self):
+        for p in self.params:
+            if not self.info[id(p)]["frozen"]:
+                p.grad = self.g(p)
+
+    def refresh_shadow(self):
+        ops.pack_shadow(self.flat_p, self.shadow, self.seg_dev, self.n_seg)
+        self._shadow_version = self.flat_p._version
+
+    def ensure_shadow_fresh(self):
+        # torch optimizers / load_state_dict write through the parameter views and bump the shared version
+        if self.flat_p._version != self._shadow_version:
+            self.refresh_shadow()
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def adamw_step(self, lr, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6, max_norm=1.0, gnorm_sq=None):
+        """Fused clip + AdamW + shadow refresh; `gnorm_sq` is a 1-element device tensor (computed here if None)."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.flat_p); self.adam_v = torch.zeros_like(self.flat_p)
+        if gnorm_sq is None:
+            gnorm_sq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            ops.sumsq(self.flat_g, gnorm_sq)
+        self.step_count += 1
+        ops.adamw_step(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.shadow, self.seg_dev, self.n_seg,
+                       gnorm_sq, max_norm, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
+        return gnorm_sq
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer executors (x, dy are token-major 2-D tensors)
+# ---------------------------------------------------------------------------------------------------------
+
+def _empty(rows, cols, like):
+    return torch.empty(rows, cols, dtype=like.dtype, device=like.device)
+
+
+def _split_k(n_out, k_in, m_red, dtype):
+    tiles = math.ceil(n_out / 128) * math.ceil(k_in / 128)
+    nkt = math.ceil(m_red / (64 if dtype == torch.bfloat16 else 32))
+    return max(1, min(512 // max(tiles, 1), nkt // 4, 64))
+
+
+def linear_fwd(x, w, bias=None, residual=None, residual2=None, out=None, out_f32=False):
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    ops.gemm(M, N, K, ops.plain(x), ops.plain(w), out, ops.pt_dtype(x), ldc=out.stride(0),
+             out_kind=L.PT_OUT_F32 if (out_f32 and x.dtype != torch.float32) else L.PT_OUT_T, bias=bias,
+             residual=residual, ldr=residual.stride(0) if residual is not None else 0,
+             residual2=residual2, ldr2=residual2.stride(0) if residual2 is not None else 0)
+    return out
+
+
+def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=None, dx_residual=None):
+    """dy [M,N]; x [M,K]; w [N,K].  Returns dx (optionally dx = dy W + dx_residual, or accumulated in place)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    pt = ops.pt_dtype(x)
+    ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
+             out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype))
+    if gbias is not None:
+        ops.colsum(dy, gbias, M, N)
+    if not need_dx:
+        return None
+    dx = dx_out if dx_out is not None else (dx_accum if dx_accum is not None else _empty(M, K, x))
+    res2 = dx_accum
+    ops.gemm(M, K, N, ops.plain(dy), ops.plain(w, trans=True), dx, pt, ldc=dx.stride(0),
+             residual=dx_residual, ldr=dx_residual.stride(0) if dx_residual is not None else 0,
+             residual2=res2, ldr2=res2.stride(0) if res2 is not None else 0)
+    return dx
+
+
+_ROWMAP_DGRAD = {L.PT_MAP_S1: L.PT_MAP_S1, L.PT_MAP_S2: L.PT_MAP_S2_DGRAD}
+
+
+def conv3_fwd(x, w3, bias, B, n_in, rowmap=L.PT_MAP_S1, cin=None, cout=None, row_bias=None, residual=None,
+              x2=None, out=None, ldc=None):
+    """Conv1d k=3 pad=1 as implicit GEMM.  x: (B*n_in, cin) token-major; w3: shadow [cout_pad][3*cin_pad]."""
+    cin = x.shape[1] if cin is None else cin
+    cout = w3.shape[0] if cout is None else cout
+    n_out = {L.PT_MAP_S1: n_in, L.PT_MAP_S2: (n_in - 1) // 2 + 1, L.PT_MAP_UP2: 2 * n_in}[rowmap]
+    M = B * n_out
+    if out is None:
+        out = _empty(M, cout, x)
+    ops.gemm(M, cout, 3 * cin, ops.conv(x, cin, n_out, n_in, rowmap), ops.plain(w3), out, ops.pt_dtype(x),
+             ldc=out.stride(0) if ldc is None else ldc, bias=bias, row_bias=row_bias, row_bias_rows=n_out,
+             residual=residual, ldr=residual.stride(0) if residual is not None else 0)
+    return out, n_out
+
+
+def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None, cout=None, cin_store=None,
+              need_dx=True, dx_residual=None):
+    """dy: (B*n_out, cout[pad]); x: (B*n_in, cin).  gw: f32 (Cout, Cin_store, 3) view of the flat grad buffer."""
+    cin = x.shape[1] if cin is None else cin
+    cout = dy.shape[1] if cout is None else cout           # channels the conv reads from dy (may be padded)
+    pt = ops.pt_dtype(x)
+    Mred = B * n_out
+    ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
+             gw, pt, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
+             conv_wgrad_cin=cin, conv_wgrad_cin_store=cin_store or cin)
+    if gbias is not None:
+        ops.colsum(dy, gbias, Mred, gbias.numel())
+    if not need_dx:
+        return None
+    if rowmap == L.PT_MAP_UP2:
+        # dgrad of (nearest x2 -> conv): stride-1 dgrad at the upsampled length, then fold row pairs
+        dxu = _empty(B * 2 * n_in, cin, x)
+        ops.gemm(B * 2 * n_in, cin, 3 * cout, ops.conv(dy, cout, 2 * n_in, n_out, L.PT_MAP_S1),
+                 ops.wflip(w3, cout, cin), dxu, pt)
+        dx = _empty(B * n_in, cin, x)
+        ops.pairsum_rows(dxu, dx)
+        return dx
+    dx = _empty(B * n_in, cin, x)
+    ops.gemm(B * n_in, cin, 3 * cout, ops.conv(dy, cout, n_in, n_out, _ROWMAP_DGRAD[rowmap]),
+             ops.wflip(w3, cout, cin), dx, pt,
+             residual=dx_residual, ldr=dx_residual.stride(0) if dx_residual is not None else 0)
+    return dx
+
+
+class GNState:
+    __slots__ = ("mean", "rstd")
+
+
+def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu):
+    C = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    s = GNState()
+    s.mean = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+    s.rstd = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+    ops.groupnorm_stats(x1, x2, s.mean, s.rstd, B, N, G, eps)
+    y = _empty(B * N, C, x1)
+    ops.groupnorm_apply(x1, x2, s.mean, s.rstd, gamma, beta, y, None, B, N, G, silu)
+    return y, s
+
+
+def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres=None):
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    ws = torch.empty(B * G * 2, dtype=torch.float32, device=x1.device)
+    ops.groupnorm_bwd(dy, x1, x2, s.mean, s.rstd, gamma, beta, dres, dx1, dx2, ggamma, gbeta, ws, B, N, G, silu)
+    return dx1, dx2
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    M = x.shape[0]
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, eps)
+    return y, (mean, rstd)
+
+
+def layernorm_bwd(dy, x, stats, gamma, ggamma, gbeta, dres=None):
+    dx = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, stats[0], stats[1], gamma, dres, dx, ggamma, gbeta)
+    return dx

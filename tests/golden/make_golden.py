@@ -134,6 +134,10 @@ def main():
         # two layers per block + different channel widths (exercises conv_shortcut on every up resnet)
         "wide": (dict(om.make_config(d=64, L=2, text_layers=2, n_q=8, T=128, S=48),
                       block_out_channels=[64, 128], attention_head_dim=32), 2, 48, 12),
+        # GPU-runnable small cases (UNet head dim = C/8 must be 32/64/128 for the MI355X attention kernels)
+        "small256": (om.make_config(d=256, L=1, text_layers=1, n_q=2, T=64, S=32), 2, 32, 21),
+        "wide256": (dict(om.make_config(d=256, L=2, text_layers=2, n_q=8, T=128, S=48),
+                         block_out_channels=[256, 512]), 2, 48, 22),
         # BASELINE config A at B=1 (d=256, 4 transformer layers, 2 codebooks, T=1024, S=256)
         "configA": (om.make_config(S=256, **om.CONFIG_A), 1, 256, 13),
     }
