@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: codec-tokens/s of the denoiser TRAINING step (BASELINE.json configs[1]) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = zero grads -> DDPM add_noise -> TTSSingleSpeaker forward -> MSE -> full backward -> [RCCL all-reduce
+of the flat grad buffer, overlapped with backward] -> global-norm clip -> fused AdamW.  Synthetic LJSpeech-shaped
+inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md:42-43
+WORKLOADS = {   # BASELINE.json configs -> 1d_config
+    "A": dict(d=256, L=1, text_layers=1, n_q=2, T=1024, B=4),
+    "B": dict(d=512, L=5, text_layers=2, n_q=8, T=1024, B=32),
+    "E": dict(d=1024, L=11, text_layers=4, n_q=8, T=2048, B=8),
+}
+
+
+def make_config(d, L, text_layers, n_q, T, S=256):
+    return {
+        "cmu_vocab_len": 149, "cmu_seq_len": S, "cross_attention_dim": d, "attention_head_dim": 64,
+        "text_encoder_dropout": 0.0, "text_encoder_layers": text_layers, "sample_size": T,
+        "in_channels": n_q, "out_channels": n_q, "layers_per_block": L, "block_out_channels": [d, d],
+        "down_block_types": ["CrossAttnDownBlock1D", "DownBlock1D"], "mid_block_type": "UNetMidBlock1DCrossAttn",
+        "up_block_types": ["UpBlock1D", "CrossAttnUpBlock1D"],
+    }
+
+
+def synthetic_batch(B, n_q, T, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    code = torch.randint(0, 1024, (B, n_q, T), generator=g)
+    x0 = ((code.double() / 1023.0).float() - 0.5) / 0.5
+    noise = torch.randn(B, n_q, T, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ids = torch.zeros(B, S, dtype=torch.int32); mask = torch.zeros(B, S, dtype=torch.int32)
+    for b in range(B):
+        L = int(torch.randint(32, S + 1, (1,), generator=g))
+        n_ph = (L - 1) // 2
+        seq = torch.full((2 * n_ph + 1,), 148, dtype=torch.int32)
+        seq[1::2] = torch.randint(1, 148, (n_ph,), generator=g, dtype=torch.int32)
+        ids[b, :seq.numel()] = seq; mask[b, :seq.numel()] = 1
+    return x0, noise, t, ids, mask
+
+
+def model_flops_per_sample(model, cfg, T, S):
+    """Algorithmic forward FLOPs (2*MAC) per sample of the GEMM/conv/attention contractions; train = 3x."""
+    from torch import nn
+    f = 0
+    N = {}
+    # walk the UNet the way fwd does, tracking the sequence length each module sees
+    u = model.unet
+    def lin(m, n): return 2 * n * m.weight.numel()
+    def attn_flops(a, nq, nk): return 4 * nq * nk * a.heads * a.dim_head
+    def block(b, n, s):
+        x = lin(b.attn1.to_q, n) + lin(b.attn1.to_k, n) + lin(b.attn1.to_v, n) + lin(b.attn1.to_out[0], n) + attn_flops(b.attn1, n, n)
+        if b.attn2 is not None:
+            x += lin(b.attn2.to_q, n) + lin(b.attn2.to_k, s) + lin(b.attn2.to_v, s) + lin(b.attn2.to_out[0], n) + attn_flops(b.attn2, n, s)
+        return x + lin(b.ff.net[0].proj, n) + lin(b.ff.net[2], n)
+    def resnet(r, n):
+        x = lin(r.conv1, n) + lin(r.conv2, n) + 2 * r.time_emb_proj.weight.numel()
+        return x + (lin(r.conv_shortcut, n) if r.conv_shortcut is not None else 0)
+    def tr(a, n): return lin(a.proj_in, n) + block(a.transformer_blocks[0], n, S)
+    for b in model.text_encoder.transformer_blocks:
+        f += block(b, S, S)
+    n = T
+    f += lin(u.conv_in, n) + 2 * (u.time_embedding.linear_1.weight.numel() + u.time_embedding.linear_2.weight.numel())
+    for blk in u.down_blocks:
+        for j, r in enumerate(blk.resnets):
+            f += resnet(r, n) + (tr(blk.attentions[j], n) if blk.attentions is not None else 0)
+        if blk.downsamplers is not None:
+            n = (n - 1) // 2 + 1
+            f += lin(blk.downsamplers[0].conv, n)
+    if u.mid_block is not None:
+        f += resnet(u.mid_block.resnets[0], n) + tr(u.mid_block.attentions[0], n) + resnet(u.mid_block.resnets[1], n)
+    for blk in u.up_blocks:
+        for j, r in enumerate(blk.resnets):
+            f += resnet(r, n) + (tr(blk.attentions[j], n) if blk.attentions is not None else 0)
+        if blk.upsamplers is not None:
+            n = 2 * n
+            f += lin(blk.upsamplers[0].conv, n)
+    f += lin(u.conv_out, n)
+    return f
+
+
+def cpu_baseline(cfg, wl, S, budget_s=20.0):
+    """The CPU oracle (oracle/train_step.py, plain PyTorch f32) timed on this box's host cores on a bounded sample."""
+    from oracle import model as om, train_step as ots
+    torch.manual_seed(0)
+    # the GPU box exposes all host cores but one GPU's share is 16: more threads only oversubscribe
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    ref = om.TTSSingleSpeaker(cfg)
+    opt = ots.make_optimizer(ref)
+    Bc = 1
+    x0, noise, t, ids, mask = synthetic_batch(Bc, wl["n_q"], wl["T"], S, 4321)
+    t0 = time.time(); ots.train_step(ref, opt, x0, noise, t, ids, mask); warm = time.time() - t0
+    steps = max(1, min(3, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(steps):
+        ots.train_step(ref, opt, x0, noise, t, ids, mask)
+    dt = (time.time() - t0) / steps
+    return {"value": Bc * wl["n_q"] * wl["T"] / dt, "unit": "codec-tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} full training step(s) of the same 1d_config at B={Bc} (f32, {dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing", action="store_true", help="per-symbol HIP-event timing of one extra step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    from prompt_tts_amd import parallel, ops
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    S = 256
+    cfg = make_config(wl["d"], wl["L"], wl["text_layers"], wl["n_q"], wl["T"], S)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                                   # identical replicas on every rank (DDP's C1 broadcast)
+    model = TTSSingleSpeaker(cfg, dtype=dtype).to(dev)
+    st = model.store
+    reducer = parallel.attach(model) if world > 1 else None
+    batch = [x.to(dev) for x in synthetic_batch(wl["B"], wl["n_q"], wl["T"], S, 1234 + rank)]
+
+    def step():
+        return model.train_step(*batch, reducer=reducer)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, per-GPU batch {wl['B']}")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        note(f"warmup step {i} done")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        loss, gnsq = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                         # HIP events on the stream every kernel is launched on
+    if world > 1:
+        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw)
+    tokens_per_step = wl["B"] * wl["n_q"] * wl["T"] * world
+    value = tokens_per_step * args.steps / wall
+
+    fwd_flops = model_flops_per_sample(model, cfg, wl["T"], S)
+    step_flops = 3 * fwd_flops * wl["B"]                   # per GPU
+    step_s = dev_ms / 1e3 / args.steps
+    achieved = step_flops / step_s / 1e12
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    out = {
+        "metric": "codec-tokens/sec (train)", "value": value, "unit": "codec-tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{ {'A': 0, 'B': 1, 'E': 4}[args.workload] }]: DDPM training step of "
+                               f"TTSSingleSpeaker d_model={wl['d']}, {2 * wl['L'] + 2} UNet transformer layers, "
+                               f"{wl['n_q']} RVQ codebooks, T_code={wl['T']}, T_text={S}",
+                   "global_batch": wl["B"] * world, "per_gpu_batch": wl["B"], "params": sum(p.numel() for p in model.parameters()),
+                   "parallelism": f"dp{world}", "optimizer": "fused AdamW + global-norm clip", "loss": float(loss)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": "whole training step (all launches of one step)",
+                     "algorithmic_flops_per_step": step_flops, "step_ms_hip_events": step_s * 1e3,
+                     "flops_per_token": 3 * fwd_flops / (wl["n_q"] * wl["T"])},
+    }
+    note(f"timed {args.steps} steps: {wall / args.steps * 1e3:.1f} ms/step")
+    if args.kernel_timing and rank == 0:
+        out["kernels"] = ops.profile_one_step(step)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, wl, S)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

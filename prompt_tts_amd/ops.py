@@ -226,3 +226,55 @@ def adamw_step(p, g, m, v, shadow, seg_dev, n_seg, gnorm_sq, max_norm, lr, beta1
 def pack_shadow(p, shadow, seg_dev, n_seg):
     check(lib.pt_pack_shadow(_p(p), _p(shadow), _p(seg_dev), n_seg, p.numel(), pt_dtype(shadow), _stream()),
           "pt_pack_shadow")
+
+
+# ---- per-symbol device timing (bench.py --kernel-timing): HIP events around every C-ABI call of one step ----------
+
+def profile_one_step(step_fn):
+    """Run step_fn() once with every pt_* call bracketed by HIP events on the launch stream.
+    Returns {label: {calls, ms_total, ms_avg, tflops (GEMM/attention), gflop_avg}} sorted by time."""
+    recs = []
+    originals = {}
+
+    def label_and_flops(name, args):
+        if name == "pt_gemm":
+            d = args[0]._obj; dt = "bf16" if args[1] == L.PT_BF16 else "f32"
+            kind = ("N", "T")[d.A.trans] + ("N", "T")[d.B.trans]
+            conv = "conv" if L.PT_V_CONV in (d.A.kind, d.B.kind) else "plain"
+            return f"gemm<{dt},{kind},{'atomic' if d.out_kind == L.PT_OUT_F32_ATOMIC else 'store'}>/{conv}", 2.0 * d.M * d.N * d.K
+        if name in ("pt_attn_fwd", "pt_attn_bwd"):
+            d = args[0]._obj
+            return name, (4.0 if name == "pt_attn_fwd" else 14.0) * d.B * d.H * d.Nq * d.Nk * d.D
+        return name, 0.0
+
+    def wrap(name, fn):
+        def inner(*args):
+            lab, fl = label_and_flops(name, args)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args)
+            e1.record()
+            recs.append((lab, fl, e0, e1))
+            return r
+        return inner
+
+    for name in L.SIGNATURES:
+        originals[name] = getattr(lib, name)
+        setattr(lib, name, wrap(name, originals[name]))
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        for name, fn in originals.items():
+            setattr(lib, name, fn)
+    agg = {}
+    for lab, fl, e0, e1 in recs:
+        a = agg.setdefault(lab, {"calls": 0, "ms_total": 0.0, "flops": 0.0})
+        a["calls"] += 1; a["ms_total"] += e0.elapsed_time(e1); a["flops"] += fl
+    out = {}
+    for lab, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms_total"]):
+        out[lab] = {"calls": a["calls"], "ms_total": round(a["ms_total"], 3), "ms_avg": round(a["ms_total"] / a["calls"], 4)}
+        if a["flops"]:
+            out[lab]["tflops"] = round(a["flops"] / (a["ms_total"] * 1e-3) / 1e12, 1)
+            out[lab]["gflop_avg"] = round(a["flops"] / a["calls"] / 1e9, 2)
+    return out

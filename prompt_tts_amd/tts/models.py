@@ -247,7 +247,8 @@ class TTSSingleSpeaker(nn.Module):
         st.zero_grad()
         if reducer is not None:
             reducer.begin()
-        loss = self.loss_and_backward(x0, noise, t, ids, mask)
+        loss = self.loss_and_backward(x0, noise, t, ids, mask,
+                                      grad_scale=reducer.grad_scale if reducer is not None else 1.0)
         if reducer is not None:
             reducer.finish()
         gn = st.adamw_step(lr, betas, eps, weight_decay, max_grad_norm)
