@@ -1,6 +1,9 @@
 // GEMM family for gfx950: C[m][n] (+)= sum_k VA(m,k) VB(n,k), 128x128 workgroup tile, 4 waves (2x2) of
-// 64x64, MFMA 16x16 atoms (mma.h), LDS double-buffered with register-staged prefetch (global loads for
-// k-tile t+1 are issued before the MFMAs of k-tile t and written to LDS after them; one barrier per k-tile).
+// 64x64, MFMA 16x16 atoms (mma.h).  Operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR
+// staging): the LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the per-lane
+// SOURCE address (and again on the fragment read); chunks that must read as zero (conv padding, M/N/K tails)
+// point at a zero page.  Two LDS stages: the loads of k-tile t+1 are in flight under the MFMAs of k-tile t,
+// one barrier per k-tile; 64 KiB LDS and <= 256 registers keep two workgroups resident per CU.
 //
 // Operands are "virtual matrices" (include/prompt_tts_hip.h): plain, channel-concat, conv-gather (implicit
 // GEMM for Conv1d k=3 stride 1/2, upsample+conv, and their dgrad/wgrad) and flipped conv weights; each is
@@ -18,6 +21,7 @@ struct VOp {
   int64_t ld, ld2, c_split;
   int kind, taps, cin, rowmap;
   int n_out, n_in;
+  int cin_shift, nout_shift;   // log2 when a power of two, else -1
   int64_t rows, cols;   // logical extent of the virtual matrix
 };
 
@@ -34,19 +38,32 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-template <typename T>
-__device__ __forceinline__ Vec16<T> vload(const VOp& op, int64_t row, int64_t col) {
-  if (row >= op.rows || col >= op.cols) return zero16<T>();
+__device__ __attribute__((aligned(256))) const uint32_t pt_zero_page[64] = {0};
+
+typedef __attribute__((address_space(1))) const void pt_gptr;
+typedef __attribute__((address_space(3))) void pt_lptr;
+
+__device__ __forceinline__ void divmod(int x, int d, int shift, int& q, int& r) {
+  if (shift >= 0) { q = x >> shift; r = x & (d - 1); }
+  else { q = x / d; r = x - q * d; }
+}
+
+// address of the 16-byte chunk V[row][col .. col+EPC) of a virtual matrix, or the zero page
+// KC = kind class, fixed at compile time so that only one addressing scheme's invariants occupy registers:
+// 0 plain / channel-concat, 1 conv gather, 2 flipped conv weights
+template <typename T, int KC>
+__device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t col) {
+  const char* zero = reinterpret_cast<const char*>(pt_zero_page);
+  if (row >= op.rows || col >= op.cols) return zero;
   const T* ptr;
-  if (op.kind == PT_V_PLAIN) {
-    ptr = reinterpret_cast<const T*>(op.p) + row * op.ld + col;
-  } else if (op.kind == PT_V_CONCAT) {
-    ptr = col < op.c_split ? reinterpret_cast<const T*>(op.p) + row * op.ld + col
-                           : reinterpret_cast<const T*>(op.p2) + row * op.ld2 + (col - op.c_split);
-  } else if (op.kind == PT_V_CONV) {
-    const int c = (int)col, r = (int)row;
-    const int tap = c / op.cin, ci = c - tap * op.cin;
-    const int b = r / op.n_out, n = r - b * op.n_out;
+  if (KC == 0) {
+    ptr = (op.kind == PT_V_PLAIN || col < op.c_split)
+              ? reinterpret_cast<const T*>(op.p) + row * op.ld + col
+              : reinterpret_cast<const T*>(op.p2) + row * op.ld2 + (col - op.c_split);
+  } else if (KC == 1) {
+    int tap, ci, b, n;
+    divmod((int)col, op.cin, op.cin_shift, tap, ci);
+    divmod((int)row, op.n_out, op.nout_shift, b, n);
     int ns; bool ok;
     const int u = n + tap - 1;
     switch (op.rowmap) {
@@ -55,25 +72,24 @@ __device__ __forceinline__ Vec16<T> vload(const VOp& op, int64_t row, int64_t co
       case PT_MAP_UP2: ns = u >> 1; ok = (u >= 0) && (u < 2 * op.n_in); break;
       default: /* PT_MAP_S2_DGRAD */ ns = u >> 1; ok = (u >= 0) && ((u & 1) == 0) && (ns < op.n_in); break;
     }
-    if (!ok) return zero16<T>();
+    if (!ok) return zero;
     ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)b * op.n_in + ns) * op.ld + ci;
   } else {  // PT_V_WFLIP: row = tap*cout + co
-    const int r = (int)row;
-    const int tap = r / op.cin, co = r - tap * op.cin;
+    int tap, co;
+    divmod((int)row, op.cin, op.cin_shift, tap, co);
     ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)co * 3 + (2 - tap)) * op.ld + col;
   }
-  return load16(ptr);
+  return reinterpret_cast<const char*>(ptr);
 }
 
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 16384;   // one operand tile image
 
-template <typename T, bool TA, bool TB, bool ATOMIC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
   constexpr int TCH = 128 / EPC;                   // chunks per TileT row (128 columns)
-  using TT = TileT<T, 128>;
   __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,40 +118,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  Vec16<T> ra[4], rb[4];
-
-  auto gload = [&](int kt) {
+  // One wave-instruction of global_load_lds writes 64 x 16 B = 1 KiB of LDS linearly (base + lane*16).  Chunk slot
+  // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
+  // data chunk (q%TCH)^swz(k): the swizzle lives in the SOURCE address.
+  const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
+  auto stage = [&](int kt, int stg) {
     const int64_t k0 = (int64_t)kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = tid + 256 * i;
-      if (!TA) ra[i] = vload<T>(p.A, m0 + (q >> 3), k0 + (q & 7) * EPC);
-      else     ra[i] = vload<T>(p.A, k0 + q / TCH, m0 + (q % TCH) * EPC);
-      if (!TB) rb[i] = vload<T>(p.B, n0 + (q >> 3), k0 + (q & 7) * EPC);
-      else     rb[i] = vload<T>(p.B, k0 + q / TCH, n0 + (q % TCH) * EPC);
-    }
-  };
-  auto lstore = [&](int stage) {
-    char* sa = smem + stage * 2 * STAGE_BYTES;
+    char* sa = smem + stg * 2 * STAGE_BYTES;
     char* sb = sa + STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 256 * i;
-      if (!TA) TileK<T>::store_chunk(sa, q >> 3, q & 7, ra[i]);
-      else     TT::store_chunk(sa, q / TCH, q % TCH, ra[i]);
-      if (!TB) TileK<T>::store_chunk(sb, q >> 3, q & 7, rb[i]);
-      else     TT::store_chunk(sb, q / TCH, q % TCH, rb[i]);
+      const char* ga; const char* gb;
+      if (!TA) { const int r = q >> 3; ga = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+      else     { const int k = q / TCH; ga = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+      if (!TB) { const int r = q >> 3; gb = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+      else     { const int k = q / TCH; gb = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+      const int lds_off = (wbase + 256 * i) * 16;
+      __builtin_amdgcn_global_load_lds((pt_gptr*)ga, (pt_lptr*)(sa + lds_off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((pt_gptr*)gb, (pt_lptr*)(sb + lds_off), 16, 0, 0);
     }
   };
 
-  gload(kt_begin);
-  lstore(0);
-  __syncthreads();
+  stage(kt_begin, 0);
+  __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = kt + 1 < kt_end;
-    if (more) gload(kt + 1);
+    if (more) stage(kt + 1, cur ^ 1);
     const char* sa = smem + cur * 2 * STAGE_BYTES;
     const char* sb = sa + STAGE_BYTES;
 #pragma unroll
@@ -160,7 +171,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           else        mma16(acc[i][j], fb[j], fa[i]);   // D[row = n][col = m]: 4 consecutive n per lane
         }
     }
-    if (more) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -251,6 +261,8 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols) {
   v.ld = o.ld; v.ld2 = o.ld2; v.c_split = o.c_split;
   v.kind = o.kind; v.taps = o.taps; v.cin = o.cin > 0 ? o.cin : 1; v.rowmap = o.rowmap;
   v.n_out = (int)(o.n_out > 0 ? o.n_out : 1); v.n_in = (int)o.n_in;
+  auto lg = [](int x) { return (x > 0 && (x & (x - 1)) == 0) ? __builtin_ctz(x) : -1; };
+  v.cin_shift = lg(v.cin); v.nout_shift = lg(v.n_out);
   v.rows = rows; v.cols = cols;
   return v;
 }
@@ -272,21 +284,34 @@ int check_operand(const pt_operand& o, int esize) {
   return PT_OK;
 }
 
-template <typename T, bool TA, bool TB>
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
 int launch(const GemmParams& p, hipStream_t s) {
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
-  if (p.out_kind == PT_OUT_F32_ATOMIC) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, false>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB>), grid, dim3(256), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
 
+inline int kind_class(int kind) { return kind == PT_V_CONV ? 1 : (kind == PT_V_WFLIP ? 2 : 0); }
+
+// Only the operand combinations the training step issues are instantiated (forward, dgrad, wgrad of linear / conv).
 template <typename T>
 int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
-  if (!ta && !tb) return launch<T, false, false>(p, s);
-  if (!ta && tb) return launch<T, false, true>(p, s);
-  if (ta && !tb) return launch<T, true, false>(p, s);
-  return launch<T, true, true>(p, s);
+  const bool atomic = p.out_kind == PT_OUT_F32_ATOMIC;
+  const int ka = kind_class(p.A.kind), kb = kind_class(p.B.kind);
+  if (!ta && !tb && !atomic && kb == 0) {                        // forward: linear / conv1x1 / conv k3
+    if (ka == 0) return launch<T, false, false, false, 0, 0>(p, s);
+    if (ka == 1) return launch<T, false, false, false, 1, 0>(p, s);
+  }
+  if (!ta && tb && !atomic) {                                    // dgrad
+    if (ka == 0 && kb == 0) return launch<T, false, true, false, 0, 0>(p, s);
+    if (ka == 1 && kb == 2) return launch<T, false, true, false, 1, 2>(p, s);
+  }
+  if (ta && tb && atomic && ka == 0) {                           // wgrad (split-K, f32 atomics)
+    if (kb == 0) return launch<T, true, true, true, 0, 0>(p, s);
+    if (kb == 1) return launch<T, true, true, true, 0, 1>(p, s);
+  }
+  return PT_ERR_ARG;
 }
 
 }  // namespace
