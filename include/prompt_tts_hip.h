@@ -31,6 +31,7 @@ enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg (binding self-check) */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.

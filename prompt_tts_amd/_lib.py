@@ -89,6 +89,11 @@ def _load():
     lib.pt_abi_version.restype = C.c_int
     lib.pt_status_string.restype = C.c_char_p
     lib.pt_status_string.argtypes = [C.c_int]
+    lib.pt_struct_size.restype = C.c_int
+    lib.pt_struct_size.argtypes = [C.c_int]
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg)):
+        if lib.pt_struct_size(i) != C.sizeof(st):
+            raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes

@@ -14,3 +14,13 @@ extern "C" const char* pt_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+extern "C" int pt_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(pt_operand);
+    case 1: return (int)sizeof(pt_gemm_desc);
+    case 2: return (int)sizeof(pt_attn_desc);
+    case 3: return (int)sizeof(pt_param_seg);
+    default: return -1;
+  }
+}

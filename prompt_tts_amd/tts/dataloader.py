@@ -1,0 +1,122 @@
+"""Collate + dataset surface of the reference (tts/dataloader.py:12-15,18-90,123-198).
+
+Hot-path row a-9 is the COLLATE: pad/truncate phoneme ids to max_seq_length with pad id 0, 1/0 mask, int32;
+codes -> float32(float64(code)/1023) -> (x-0.5)/0.5.  It is CPU-side, integer/byte work on tiny arrays and
+runs on the host exactly as in the reference (numpy), producing the same batch dictionary keys.
+
+The text front-end (tts/process_text/*: unidecode + inflect + CMUdict) is out of scope this round (SURVEY 2.1 #9,
+8f-2): SingleSpeakerDataset takes a `text_to_ids` callable (the reference's text_to_sequence fits) or reads
+precomputed `<utt>.cmu.npy` id arrays from the tar.
+"""
+import io
+import tarfile
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+BLANK_ID = 148          # len(symbols) in tts/process_text/symbols.py: the interspersed blank (dataloader.py:52-55)
+
+
+def intersperse(lst, item):
+    result = [item] * (len(lst) * 2 + 1)
+    result[1::2] = lst
+    return result
+
+
+def _collate_batch_helpler(examples, pad_token_id, max_length, return_mask=False):
+    """(name kept from the reference, typo included) -> python lists, like the reference."""
+    ids = np.full((len(examples), max_length), pad_token_id, dtype=np.int64)
+    mask = np.zeros((len(examples), max_length), dtype=np.int64)
+    for i, ex in enumerate(examples):
+        n = min(len(ex), max_length)
+        ids[i, :n] = np.asarray(ex[:n], dtype=np.int64)
+        mask[i, :n] = 1
+    if return_mask:
+        return ids.tolist(), mask.tolist()
+    return ids.tolist()
+
+
+def normalise_codes(code_over_1023):
+    """torch.FloatTensor(np.array(batch_code)) then torchvision Normalize([0.5],[0.5]) (dataloader.py:143,169)."""
+    x = torch.from_numpy(np.asarray(code_over_1023, dtype=np.float64).astype(np.float32))
+    return (x - 0.5) / 0.5
+
+
+class TTS_SingleSpkr_Collate_Fn(object):
+    def __init__(self, max_seq_length):
+        self.max_seq_length = max_seq_length
+
+    def __call__(self, batch):
+        cmu = [it["cmu_sequence"] for it in batch]
+        cmu_seq, cmu_mask = _collate_batch_helpler(cmu, 0, self.max_seq_length, return_mask=True)
+        out = {
+            "code": normalise_codes(np.array([it["code"] for it in batch])),
+            "text": [it["text"] for it in batch],
+            "code_length": [it["code_length"] for it in batch],
+            "cmu_sequence": cmu,
+            "cmu_sequence_id": torch.tensor(cmu_seq, dtype=torch.int32),
+            "attention_mask": torch.tensor(cmu_mask, dtype=torch.int32),
+        }
+        if "text_norm" in batch[0]:
+            out["text_norm"] = [it["text_norm"] for it in batch]
+        return out
+
+
+class SingleSpeakerDataset(Dataset):
+    """Whole tar in RAM, as the reference: <utt>.npy (int64 [n_q,T]), <utt>.txt, [<utt>.normalized.txt], <utt>.len.txt."""
+
+    def __init__(self, data_path, text_to_ids=None):
+        super().__init__()
+        self.item_list = []
+        with tarfile.open(data_path, "r") as tf:
+            names = {m.name for m in tf.getmembers()}
+            for name in sorted(n for n in names if n.endswith(".npy") and not n.endswith(".cmu.npy")):
+                stem = name[:-4]
+                code = np.load(io.BytesIO(tf.extractfile(name).read()))
+                text = tf.extractfile(stem + ".txt").read().decode()
+                has_norm = stem + ".normalized.txt" in names
+                text_norm = tf.extractfile(stem + ".normalized.txt").read().decode() if has_norm else text
+                if stem + ".cmu.npy" in names:
+                    ids = np.load(io.BytesIO(tf.extractfile(stem + ".cmu.npy").read())).tolist()
+                elif text_to_ids is not None:
+                    ids = list(text_to_ids(text_norm))
+                else:
+                    raise NotImplementedError(
+                        "the CMUdict text front-end is outside this build's scope: pass text_to_ids=... "
+                        "(e.g. the reference's text_to_sequence) or ship <utt>.cmu.npy phoneme ids in the tar")
+                item = {"code": code / 1023, "text": text, "cmu_sequence": intersperse(ids, BLANK_ID),
+                        "code_length": float(tf.extractfile(stem + ".len.txt").read().decode())}
+                if has_norm:
+                    item["text_norm"] = text_norm
+                self.item_list.append(item)
+
+    def __len__(self):
+        return len(self.item_list)
+
+    def __getitem__(self, idx):
+        return self.item_list[idx]
+
+
+class SyntheticDataset(Dataset):
+    """LJSpeech-shaped synthetic items: codes U{0..1023}, phoneme ids U{1..147} blank-interspersed."""
+
+    def __init__(self, n_items, n_q, T, max_text=256, seed=1234):
+        g = np.random.default_rng(seed)
+        self.item_list = []
+        for i in range(n_items):
+            n_ph = int(g.integers(16, max(17, (max_text - 1) // 2 + 1)))
+            self.item_list.append({
+                "code": g.integers(0, 1024, (n_q, T)).astype(np.int64) / 1023, "text": f"synthetic {i}",
+                "cmu_sequence": intersperse(g.integers(1, 148, n_ph).tolist(), BLANK_ID), "code_length": float(T)})
+
+    def __len__(self):
+        return len(self.item_list)
+
+    def __getitem__(self, idx):
+        return self.item_list[idx]
+
+
+def create_dataloader(data_file, batch_size, max_seq_length, shuffle=False, text_to_ids=None, dataset=None):
+    dataset = dataset if dataset is not None else SingleSpeakerDataset(data_file, text_to_ids)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=TTS_SingleSpkr_Collate_Fn(max_seq_length))

@@ -1,0 +1,131 @@
+"""CPU: host logic -- collate parity, C-ABI surface, product/oracle separation, model construction, LR schedule."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _items(rng, n, n_q=2, T=12, with_norm=False, lens=(0, 3, 40)):
+    out = []
+    for i in range(n):
+        L = lens[i % len(lens)]
+        it = {"code": rng.integers(0, 1024, (n_q, T)).astype(np.int64) / 1023, "text": f"t{i}",
+              "cmu_sequence": rng.integers(1, 149, L).tolist(), "code_length": float(T - i)}
+        if with_norm:
+            it["text_norm"] = f"n{i}"
+        out.append(it)
+    return out
+
+
+@pytest.mark.parametrize("with_norm", [False, True])
+def test_collate_bit_exact_vs_oracle(with_norm):
+    from oracle import collate as oc
+    from prompt_tts_amd.tts.dataloader import TTS_SingleSpkr_Collate_Fn, intersperse
+    rng = np.random.default_rng(0)
+    items = _items(rng, 5, with_norm=with_norm)              # empty, short and over-long (truncated) sequences
+    got = TTS_SingleSpkr_Collate_Fn(16)(items)
+    want = oc.collate([dict(it, code_int=np.rint(it["code"] * 1023).astype(np.int64)) for it in items], 16)
+    assert got["cmu_sequence_id"].dtype == torch.int32 and got["attention_mask"].dtype == torch.int32
+    assert np.array_equal(got["cmu_sequence_id"].numpy(), want["cmu_sequence_id"])            # bit-exact ints
+    assert np.array_equal(got["attention_mask"].numpy(), want["attention_mask"])
+    assert got["code"].dtype == torch.float32 and np.array_equal(got["code"].numpy(), want["code"])  # bit-exact f32
+    assert set(got) == set(want) and ("text_norm" in got) == with_norm
+    assert got["attention_mask"][0].sum() == 0 and got["attention_mask"][2].sum() == 16
+    assert intersperse([5, 6], 148) == [148, 5, 148, 6, 148] == oc.intersperse([5, 6], 148)
+    # round trip of the code normalisation through the build-defined inverse
+    codes = rng.integers(0, 1024, (3, 8, 50))
+    assert np.array_equal(oc.denormalise_to_codes(oc.normalise_codes(codes)), codes)
+
+
+def test_dataset_from_tar_and_loader(tmp_path):
+    import io
+    import tarfile
+    from prompt_tts_amd.tts.dataloader import SingleSpeakerDataset, create_dataloader
+    rng = np.random.default_rng(1)
+    path = tmp_path / "d.tar"
+    with tarfile.open(path, "w") as tf:
+        def add(name, data):
+            ti = tarfile.TarInfo(name); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+        for u in ("a", "b", "c"):
+            buf = io.BytesIO(); np.save(buf, rng.integers(0, 1024, (2, 20))); add(f"{u}.npy", buf.getvalue())
+            add(f"{u}.txt", b"hello world"); add(f"{u}.len.txt", b"19.0")
+            if u != "c":
+                add(f"{u}.normalized.txt", b"hello world")
+    with pytest.raises(NotImplementedError):
+        SingleSpeakerDataset(str(path))
+    dl = create_dataloader(str(path), 2, 8, text_to_ids=lambda s: [ord(c) % 147 + 1 for c in s])
+    b = next(iter(dl))
+    assert b["code"].shape == (2, 2, 20) and b["cmu_sequence_id"].shape == (2, 8)
+    assert b["cmu_sequence"][0][0] == 148 and float(b["code"].abs().max()) <= 1.0
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "prompt_tts_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(pt_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 27
+    from prompt_tts_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared - {"pt_abi_version", "pt_status_string", "pt_struct_size"} == set(_lib.SIGNATURES)          # binding == header
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (pt_\w+)", out))
+    assert exported >= declared
+    assert _lib.lib.pt_abi_version() >= 2
+    assert b"aligned" in _lib.lib.pt_status_string(-4)
+    # argument validation returns before any HIP call: safe without a GPU
+    assert _lib.lib.pt_gemm(None, 1, None) == -5
+    d = _lib.pt_gemm_desc(); d.M = d.N = d.K = 0
+    assert _lib.lib.pt_gemm(ctypes.byref(d), 1, None) == -1
+    assert _lib.lib.pt_gemm(ctypes.byref(d), 7, None) == -2
+    assert _lib.lib.pt_attn_fwd(None, 1, None) == -5
+    for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg)):
+        assert _lib.lib.pt_struct_size(i) == ctypes.sizeof(st)          # the ctypes mirror matches the C layout
+
+
+def test_product_never_imports_oracle_or_reference():
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|tts\.)", re.M)
+    for base in ("prompt_tts_amd",):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert not pat.search(txt), f"{f} imports the oracle"
+                    assert "/root/reference" not in txt
+    assert "oracle" not in open(os.path.join(ROOT, "train.py")).read()
+
+
+def test_model_constructs_on_cpu_with_reference_keys_and_refuses_cpu_compute():
+    from oracle import model as om
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    cfg = om.make_config(d=64, L=1, text_layers=1, n_q=2, T=64, S=32)
+    ref = om.TTSSingleSpeaker(cfg)
+    m = TTSSingleSpeaker(cfg)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict())                      # checkpoints interchange with the reference layout
+    for k, v in ref.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 2, 64), 3, torch.zeros(1, 32, dtype=torch.int32), torch.ones(1, 32, dtype=torch.int32))
+    with pytest.raises(ValueError):
+        TTSSingleSpeaker(dict(cfg, up_block_types=["UpBlock1D", "Bogus"]))
+    with pytest.raises(ValueError):
+        TTSSingleSpeaker(dict(cfg, attention_head_dim=48))
+
+
+def test_train_lr_lambda_matches_oracle():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_mod", os.path.join(ROOT, "train.py"))
+    src = open(os.path.join(ROOT, "train.py")).read()
+    ns = {}
+    exec(compile(src[src.index("def lr_lambda"):src.index("def main")], "train_lr", "exec"), {"math": __import__("math")}, ns)
+    from oracle.blocks import lr_lambda as want
+    for name in ("constant", "constant_with_warmup", "linear", "cosine"):
+        f, g = ns["lr_lambda"](name, 5, 40), want(name, 5, 40)
+        assert all(abs(f(s) - g(s)) < 1e-12 for s in range(0, 45))

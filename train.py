@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's CLI and 1d_config schema (train.py:21-172), MI355X-native inside.
+
+  accelerate launch train.py --data_file d.tar --log_dir logs --config_file 1d_config.json --ckpt_dir ckpt/
+  python -m torch.distributed.run --nproc-per-node 8 train.py ...        (same thing; one process per GPU)
+  python train.py --synthetic 256 --config_file ... --log_dir ... --ckpt_dir ...   (no tar needed)
+
+Differences from the reference, all behind the same surface: the step is the fused HIP path
+(TTSSingleSpeaker.train_step: add_noise -> forward -> MSE -> backward -> clip -> AdamW, no host sync except the
+logged loss), data parallelism is a bucketed RCCL all-reduce of the flat grad buffer overlapped with backward
+(prompt_tts_amd/parallel.py) instead of DDP(find_unused_parameters=True), and the batch sharding follows
+accelerate's BatchSamplerShard round-robin (rank r takes batches r, r+W, ...).
+"""
+import argparse
+import json
+import logging
+import math
+import os
+
+import torch
+
+from prompt_tts_amd import parallel
+from prompt_tts_amd.tts.dataloader import SyntheticDataset, create_dataloader
+from prompt_tts_amd.tts.models import TTSSingleSpeaker
+
+logging.basicConfig(format="%(asctime)s - %(levelname)s: %(message)s", level=logging.INFO, datefmt="%I:%M:%S")
+
+ADAMW = dict(lr=1e-5, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)      # hard-coded in the reference (train.py:41-47)
+
+
+def lr_lambda(name, num_warmup_steps, num_training_steps):
+    """diffusers.optimization.get_scheduler multipliers for the names the 1d_config may carry (train.py:60-65)."""
+    w, n = num_warmup_steps, num_training_steps
+    if name == "constant":
+        return lambda s: 1.0
+    if name == "constant_with_warmup":
+        return lambda s: float(s) / float(max(1.0, w)) if s < w else 1.0
+    if name == "linear":
+        return lambda s: float(s) / float(max(1, w)) if s < w else max(0.0, float(n - s) / float(max(1, n - w)))
+    if name == "cosine":
+        return lambda s: (float(s) / float(max(1, w)) if s < w else
+                          max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(s - w) / float(max(1, n - w))))))
+    raise ValueError(f"unsupported lr_scheduler {name!r}")
+
+
+def main(args):
+    config = json.load(open(args.config_file, "r"))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        writer = SummaryWriter(log_dir=args.log_dir) if rank == 0 else None
+    except Exception:                                                       # tensorboard is optional here
+        writer = None
+
+    torch.manual_seed(0)
+    model = TTSSingleSpeaker(config, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
+    reducer = parallel.attach(model) if world > 1 else None
+    ds = SyntheticDataset(args.synthetic, config["in_channels"], config["sample_size"], args.max_seq_length) if args.synthetic else None
+    dataloader = create_dataloader(args.data_file, args.batch_size, args.max_seq_length, shuffle=True, dataset=ds)
+    accum = config["gradient_accumulation_steps"]
+    steps_per_epoch = math.ceil(math.ceil(len(dataloader) / world) / accum)
+    max_train_steps = config["num_train_epochs"] * steps_per_epoch
+    lam = lr_lambda(config["lr_scheduler"], config["lr_warmup_steps"] * accum, max_train_steps * accum)
+    st = model.store
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    global_step = opt_step = 0
+    for epoch in range(config["num_train_epochs"]):
+        logging.info(f"Starting epoch {epoch}:")
+        torch.manual_seed(epoch)                                            # same shuffle on every rank (accelerate C7)
+        micro = 0
+        loss_acc = torch.zeros(1, device=dev)
+        for bi, batch in enumerate(dataloader):
+            if bi % world != rank:                                          # BatchSamplerShard round-robin
+                continue
+            codes = batch["code"].to(dev)
+            ids = batch["cmu_sequence_id"].to(dev); mask = batch["attention_mask"].to(dev)
+            noise = torch.randn(codes.shape, device=dev, generator=gen)
+            t = torch.randint(0, 1000, (codes.shape[0],), device=dev, generator=gen)
+            if micro == 0:
+                st.zero_grad()
+                if reducer is not None:
+                    reducer.begin()
+            model.grad_ready_hook = reducer.on_ready if (reducer is not None and micro == accum - 1) else None
+            model.loss_and_backward(codes, noise, t, ids, mask, loss_out=loss_acc,
+                                    grad_scale=1.0 / (accum * world))
+            micro += 1
+            global_step += 1
+            if micro == accum:
+                if reducer is not None:
+                    reducer.finish()
+                st.adamw_step(ADAMW["lr"] * lam(opt_step), ADAMW["betas"], ADAMW["eps"], ADAMW["weight_decay"], 1.0)
+                opt_step += 1; micro = 0
+                if opt_step % args.log_every == 0:
+                    if world > 1:
+                        torch.distributed.all_reduce(loss_acc, op=torch.distributed.ReduceOp.AVG)
+                    train_loss = float(loss_acc) / accum                    # the only host sync
+                    if rank == 0:
+                        logging.info(f"step {opt_step}: MSE={train_loss:.6f}")
+                        if writer is not None:
+                            writer.add_scalar("Loss/train", train_loss, global_step)
+                loss_acc.zero_()
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0 and epoch % config["save_per_epochs"] == 0:
+            # same file names as the reference, which concatenates ckpt_dir and the name without a separator
+            torch.save(model.state_dict(), args.ckpt_dir + f"ckpt_{epoch + 1}.pt")
+            torch.save({"step": st.step_count, "exp_avg": st.adam_m, "exp_avg_sq": st.adam_v, "names": st.names},
+                       args.ckpt_dir + f"optim_{epoch + 1}.pt")
+    if writer is not None:
+        writer.flush(); writer.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="Train TTS models. The data is stored in WebDataset format.")
+    p.add_argument("--data_file", type=str, default=None, help="Path to the training data file.")
+    p.add_argument("--log_dir", type=str, required=True, help="Directory to save logs.")
+    p.add_argument("--config_file", type=str, required=True, help="Path to config file.")
+    p.add_argument("--ckpt_dir", type=str, required=True, help="Directory to save checkpoints.")
+    p.add_argument("--batch_size", type=int, default=32, help="Per-process batch size.")
+    p.add_argument("--max_seq_length", type=int, default=550, help="Maximum length of cmu sequence.")
+    p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic LJSpeech-shaped items instead of a tar")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--log_every", type=int, default=10)
+    a = p.parse_args()
+    if not a.synthetic and not a.data_file:
+        p.error("--data_file is required (or --synthetic N)")
+    return a
+
+
+if __name__ == "__main__":
+    main(parse_args())
