@@ -113,6 +113,27 @@ def cpu_baseline(cfg, wl, S, budget_s=20.0):
             "kind": "port", "sample": f"{steps} full training step(s) of the same 1d_config at B={Bc} (f32, {dt:.2f} s/step)"}
 
 
+def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
+    """BASELINE configs[3] second half: Encodec 24 kHz decode of `prompts` x T frames -> generated-audio-seconds/s."""
+    from decode_codec import random_decoder_weights
+    from prompt_tts_amd.encodec import EncodecDecoder
+    dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=dtype)
+    codes = torch.randint(0, 1024, (prompts, 8, T), generator=torch.Generator().manual_seed(7)).to(dev)
+    dec.decode(codes); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        wav = dec.decode(codes)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    audio_s = prompts * T / 75.0
+    flops = 2 * 19863552 * prompts * T                     # 19.86 M MAC per frame (SURVEY 8d)
+    return {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
+            "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "lstm_steps_per_s": 2 * T / (ms * 1e-3), "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+            "weights": "seeded random (no checkpoint offline)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +143,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the Encodec decode leg (audio-s/s)")
     ap.add_argument("--kernel-timing", action="store_true", help="per-symbol HIP-event timing of one extra step")
     args = ap.parse_args()
 
@@ -208,6 +230,9 @@ def main():
     note(f"timed {args.steps} steps: {wall / args.steps * 1e3:.1f} ms/step")
     if args.kernel_timing and rank == 0:
         out["kernels"] = ops.profile_one_step(step)
+    if rank == 0 and world == 1 and not args.no_decode:
+        note("decode leg (configs[3]: 64 prompts x 1024 frames)")
+        out["decode"] = decode_bench(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl, S)
     if rank == 0:

@@ -31,7 +31,7 @@ enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg (binding self-check) */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -51,7 +51,9 @@ enum pt_rowmap {    /* src(n, tap) for PT_V_CONV; "invalid" rows read as zero */
   PT_MAP_S1 = 0,        /* n + tap - 1                    (conv k3 stride 1, pad 1)                    */
   PT_MAP_S2 = 1,        /* 2n + tap - 1                   (conv k3 stride 2, pad 1)                    */
   PT_MAP_UP2 = 2,       /* (n + tap - 1) >> 1 over 2*n_in (nearest x2 upsample, then conv k3)          */
-  PT_MAP_S2_DGRAD = 3   /* u = n + tap - 1 ; u even ? u/2 : invalid   (dgrad of the stride-2 conv)     */
+  PT_MAP_S2_DGRAD = 3,  /* u = n + tap - 1 ; u even ? u/2 : invalid   (dgrad of the stride-2 conv)     */
+  PT_MAP_CAUSAL_REFLECT = 4, /* u = n + tap - (taps-1) ; u < 0 ? -u : u   (Encodec causal conv, reflect left pad) */
+  PT_MAP_BACK = 5       /* u = n - tap ; u < 0 invalid                (the two taps of a stride-r transposed conv) */
 };
 
 typedef struct pt_operand {
@@ -83,6 +85,9 @@ typedef struct pt_gemm_desc {
   int32_t conv_wgrad_cin;        /* > 0: C index (m, n=tap*cin+ci) -> m*3*cin + ci*3 + tap (reference Conv1d weight layout) */
   int32_t conv_wgrad_cin_store;  /* real Cin of the stored weight when cin is padded (conv_in)    */
   float alpha;                   /* scales the accumulator before the epilogue adds               */
+  int32_t act;                   /* 0 none, 1 ELU(alpha=1) applied to what is stored in C         */
+  int32_t act2;                  /* same for the optional second output                            */
+  void* C2; int64_t ldc2;        /* optional second store of the same tile (e.g. raw + ELU), or NULL */
 } pt_gemm_desc;
 
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
@@ -205,6 +210,44 @@ int pt_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, co
 /* shadow refresh only (after load_state_dict). */
 int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
                    int dtype, pt_stream stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Encodec 24 kHz decoder (decode_codec.py:12-16 -> encodec.EncodecModel.decode).
+ * Token-major activations (B*N, C); weights are EFFECTIVE (weight-norm folded on the host at load time).
+ * Big layers (conv k7 128->512, the transposed convs, the C>=128 residual blocks) run on pt_gemm with the
+ * PT_MAP_CAUSAL_REFLECT / PT_MAP_BACK row maps; the kernels below cover what a 128x128 GEMM tile cannot.
+ * ---------------------------------------------------------------------------------------------- */
+/* RVQ decode: out[(b,t)][:] = sum_q codebooks[q][codes[b][q][t]][:]   (codes int64 (B,n_q,T); dim multiple of 8). */
+int pt_rvq_decode(const int64_t* codes, const void* codebooks, void* out, int64_t B, int64_t n_q, int64_t T,
+                  int64_t bins, int64_t dim, int dtype, pt_stream stream);
+
+/* Row-streaming conv for few output channels (N <= 64): y[m][n] = act(bias[n] + sum_k A(m,k) w[n][k]) with
+ * A(m, tap*cin+ci) = f(x[(b, src(n_row,tap))][ci]) for k < taps*cin and A(m, taps*cin + c) = f2(x2[m][c]) after that
+ * (f, f2 = identity or ELU).  Weights stay in registers, rows stream HBM -> MFMA fragments directly, no LDS.
+ * HBM-bound: bytes = M * (cin + cin2 + N) * sizeof(T) (tap re-reads are L1/L2 hits). */
+typedef struct pt_rowconv_desc {
+  int64_t B, n_rows;               /* M = B * n_rows output rows; taps never cross a batch item            */
+  const void* x; int64_t ldx; int32_t cin; int32_t taps; int32_t rowmap; int32_t elu_x;
+  const void* x2; int64_t ldx2; int32_t cin2; int32_t elu_x2;
+  const void* w; int64_t ldw;      /* [N][ldw], ldw = K rounded up to 32, zero padded                       */
+  const float* bias; int32_t N; int32_t act;   /* act: 0 none, 1 ELU                                        */
+  void* y; int64_t ldy; int32_t y_f32; int32_t _pad;
+} pt_rowconv_desc;
+int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream);
+
+/* Two-layer LSTM(H) over T steps + skip + ELU (encodec SLSTM; gate order i,f,g,o as torch.nn.LSTM):
+ *   xg0   [B*T][4H]  = x W_ih0^T + b_ih0 + b_hh0  (computed by the caller with pt_gemm)
+ *   layer 1 uses wcat1 [4H][2H] = [W_ih1 | W_hh1] and bias1 [4H] = b_ih1 + b_hh1
+ *   out_elu[(b,t)][:] = ELU(h1_t + x[(b,t)][:])
+ * h0_seq, h1_seq [B*T][H] and c0, c1 [B][H] (f32) are caller-provided scratch.  The library issues T+1 dependent
+ * launches (layer 0 step s beside layer 1 step s-1); latency-bound: reports steps/s, not a roofline fraction. */
+typedef struct pt_lstm2_desc {
+  int64_t B, T, H;
+  const void* x; const void* xg0; const void* whh0; const void* wcat1; const float* bias1;
+  void* h0_seq; void* h1_seq; float* c0; float* c1; void* out_elu;
+} pt_lstm2_desc;
+int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
 
 PT_F32, PT_BF16 = 0, 1
 PT_V_PLAIN, PT_V_CONCAT, PT_V_CONV, PT_V_WFLIP = 0, 1, 2, 3
-PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD = 0, 1, 2, 3
+PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD, PT_MAP_CAUSAL_REFLECT, PT_MAP_BACK = 0, 1, 2, 3, 4, 5
 PT_OUT_T, PT_OUT_F32, PT_OUT_F32_ATOMIC = 0, 1, 2
 
 
@@ -28,7 +28,8 @@ class pt_gemm_desc(C.Structure):
                 ("bias", C.c_void_p), ("row_bias", C.c_void_p), ("row_bias_rows", C.c_int64),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("residual2", C.c_void_p), ("ldr2", C.c_int64),
                 ("conv_wgrad_cin", C.c_int32),
-                ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float)]
+                ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
+                ("C2", C.c_void_p), ("ldc2", C.c_int64)]
 
 
 class pt_attn_desc(C.Structure):
@@ -39,6 +40,20 @@ class pt_attn_desc(C.Structure):
                 ("d_o", C.c_void_p), ("lddo", C.c_int64), ("delta", C.c_void_p),
                 ("dq", C.c_void_p), ("lddq", C.c_int64), ("dk", C.c_void_p), ("lddk", C.c_int64),
                 ("dv", C.c_void_p), ("lddv", C.c_int64)]
+
+
+class pt_rowconv_desc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("n_rows", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("cin", C.c_int32),
+                ("taps", C.c_int32), ("rowmap", C.c_int32), ("elu_x", C.c_int32), ("x2", C.c_void_p), ("ldx2", C.c_int64),
+                ("cin2", C.c_int32), ("elu_x2", C.c_int32), ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+                ("N", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int64), ("y_f32", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class pt_lstm2_desc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("H", C.c_int64), ("x", C.c_void_p), ("xg0", C.c_void_p),
+                ("whh0", C.c_void_p), ("wcat1", C.c_void_p), ("bias1", C.c_void_p), ("h0_seq", C.c_void_p),
+                ("h1_seq", C.c_void_p), ("c0", C.c_void_p), ("c1", C.c_void_p), ("out_elu", C.c_void_p)]
 
 
 class pt_param_seg(C.Structure):
@@ -77,6 +92,9 @@ SIGNATURES = {
     "pt_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
                       _i32, _vp],
     "pt_pack_shadow": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_rvq_decode": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_rowconv": [C.POINTER(pt_rowconv_desc), _i32, _vp],
+    "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],
 }
 
 
@@ -91,7 +109,7 @@ def _load():
     lib.pt_status_string.argtypes = [C.c_int]
     lib.pt_struct_size.restype = C.c_int
     lib.pt_struct_size.argtypes = [C.c_int]
-    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg)):
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():

@@ -78,16 +78,5 @@ __device__ __forceinline__ void frag_from_acc(Frag<T>& f, const f32x4_t& lo, con
   frag_from_f32(f, x);
 }
 
-// store 4 consecutive elements of an output row
-template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d};
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  u32x2_t o;
-  o[0] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
-  o[1] = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
-  *reinterpret_cast<u32x2_t*>(p) = o;
-}
 
 #define PT_LOG2E 1.4426950408889634f

@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 2; }
+extern "C" int pt_abi_version(void) { return 3; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
@@ -21,6 +21,8 @@ extern "C" int pt_struct_size(int which) {
     case 1: return (int)sizeof(pt_gemm_desc);
     case 2: return (int)sizeof(pt_attn_desc);
     case 3: return (int)sizeof(pt_param_seg);
+    case 4: return (int)sizeof(pt_rowconv_desc);
+    case 5: return (int)sizeof(pt_lstm2_desc);
     default: return -1;
   }
 }

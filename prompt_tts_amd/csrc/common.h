@@ -58,6 +58,19 @@ template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<
 }
 template <typename T> __device__ __forceinline__ Vec16<T> zero16() { Vec16<T> v; v.raw = (u32x4_t){0, 0, 0, 0}; return v; }
 
+
+// store 4 consecutive elements of an output row
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  u32x2_t o;
+  o[0] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  o[1] = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  *reinterpret_cast<u32x2_t*>(p) = o;
+}
+
 // ---- reductions ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -35,6 +35,7 @@ struct GemmParams {
   const char* residual2; int64_t ldr2;
   int conv_wgrad_cin, conv_wgrad_cin_store;
   float alpha;
+  int act, act2; char* C2; int64_t ldc2;
   int tiles_m, tiles_n;
 };
 
@@ -70,7 +71,9 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
       case PT_MAP_S1: ns = u; ok = (u >= 0) && (u < op.n_in); break;
       case PT_MAP_S2: ns = 2 * n + tap - 1; ok = (ns >= 0) && (ns < op.n_in); break;
       case PT_MAP_UP2: ns = u >> 1; ok = (u >= 0) && (u < 2 * op.n_in); break;
-      default: /* PT_MAP_S2_DGRAD */ ns = u >> 1; ok = (u >= 0) && ((u & 1) == 0) && (ns < op.n_in); break;
+      case PT_MAP_S2_DGRAD: ns = u >> 1; ok = (u >= 0) && ((u & 1) == 0) && (ns < op.n_in); break;
+      case PT_MAP_CAUSAL_REFLECT: { const int v = n + tap - (op.taps - 1); ns = v < 0 ? -v : v; ok = ns < op.n_in; } break;
+      default: /* PT_MAP_BACK */ ns = n - tap; ok = ns >= 0; break;
     }
     if (!ok) return zero;
     ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)b * op.n_in + ns) * op.ld + ci;
@@ -227,19 +230,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
         }
-        if (p.out_kind == PT_OUT_F32) {
-          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
-        } else {
-          T* cp = reinterpret_cast<T*>(p.C) + m * p.ldc + n;
-          if (sizeof(T) == 4) {
-            *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        auto put = [&](char* base, int64_t ld, int act) {
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[r] < 0.f) ? (__expf(v[r]) - 1.f) : v[r];
+          if (p.out_kind == PT_OUT_F32) {
+            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(base) + m * ld + n) = (f32x4_t){w[0], w[1], w[2], w[3]};
+          } else if (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(base) + m * ld + n) = (f32x4_t){w[0], w[1], w[2], w[3]};
           } else {
             u32x2_t o;
-            o[0] = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-            *reinterpret_cast<u32x2_t*>(cp) = o;
+            o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+            *reinterpret_cast<u32x2_t*>(reinterpret_cast<T*>(base) + m * ld + n) = o;
           }
-        }
+        };
+        put(p.C, p.ldc, p.act);
+        if (p.C2) put(p.C2, p.ldc2, p.act2);
       } else {
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
           float x = v[r];
@@ -247,8 +254,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           if (rbias) x += rbias[n + r];
           if (p.residual) x += to_f32<T>(reinterpret_cast<const T*>(p.residual)[m * p.ldr + n + r]);
           if (p.residual2) x += to_f32<T>(reinterpret_cast<const T*>(p.residual2)[m * p.ldr2 + n + r]);
-          if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C)[m * p.ldc + n + r] = x;
-          else reinterpret_cast<T*>(p.C)[m * p.ldc + n + r] = from_f32<T>(x);
+          const float x1 = (p.act == 1 && x < 0.f) ? (__expf(x) - 1.f) : x;
+          if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C)[m * p.ldc + n + r] = x1;
+          else reinterpret_cast<T*>(p.C)[m * p.ldc + n + r] = from_f32<T>(x1);
+          if (p.C2) {
+            const float x2 = (p.act2 == 1 && x < 0.f) ? (__expf(x) - 1.f) : x;
+            if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C2)[m * p.ldc2 + n + r] = x2;
+            else reinterpret_cast<T*>(p.C2)[m * p.ldc2 + n + r] = from_f32<T>(x2);
+          }
         }
       }
     }
@@ -273,9 +286,10 @@ int check_operand(const pt_operand& o, int esize) {
   if (o.kind == PT_V_CONCAT) {
     if (!o.p2 || !pt_aligned16(o.p2) || (o.ld2 * esize) % 16 != 0 || (o.c_split * esize) % 16 != 0) return PT_ERR_ALIGN;
   } else if (o.kind == PT_V_CONV) {
-    if (o.taps != 3 && o.taps != 1) return PT_ERR_ARG;
+    if (o.taps < 1 || o.taps > 16) return PT_ERR_ARG;
     if (o.cin <= 0 || (o.cin * esize) % 16 != 0 || o.n_out <= 0 || o.n_in <= 0) return PT_ERR_SHAPE;
-    if (o.rowmap < PT_MAP_S1 || o.rowmap > PT_MAP_S2_DGRAD) return PT_ERR_ARG;
+    if (o.rowmap < PT_MAP_S1 || o.rowmap > PT_MAP_BACK) return PT_ERR_ARG;
+    if (o.rowmap == PT_MAP_CAUSAL_REFLECT && o.n_in < o.taps) return PT_ERR_SHAPE;   // reflect needs n_in > pad
   } else if (o.kind == PT_V_WFLIP) {
     if (o.cin <= 0) return PT_ERR_SHAPE;
   } else if (o.kind != PT_V_PLAIN) {
@@ -328,13 +342,14 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   if (!d->C) return PT_ERR_ARG;
   if (d->out_kind < PT_OUT_T || d->out_kind > PT_OUT_F32_ATOMIC) return PT_ERR_ARG;
   if (d->split_k < 1 || (d->split_k > 1 && d->out_kind != PT_OUT_F32_ATOMIC)) return PT_ERR_ARG;
-  if (d->out_kind == PT_OUT_F32_ATOMIC && (d->bias || d->row_bias || d->residual || d->residual2)) return PT_ERR_ARG;
+  if (d->out_kind == PT_OUT_F32_ATOMIC && (d->bias || d->row_bias || d->residual || d->residual2 || d->C2 || d->act)) return PT_ERR_ARG;
   if (d->out_kind != PT_OUT_F32_ATOMIC) {
     const int oes = d->out_kind == PT_OUT_F32 ? 4 : es;
     if ((reinterpret_cast<uintptr_t>(d->C) & 15u) || (d->ldc * oes) % (4 * oes) != 0) return PT_ERR_ALIGN;
     if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15u)) return PT_ERR_ALIGN;
     if (d->row_bias && ((reinterpret_cast<uintptr_t>(d->row_bias) & 15u) || d->row_bias_rows <= 0 || (d->N % 4))) return PT_ERR_ALIGN;
     if (d->conv_wgrad_cin > 0) return PT_ERR_ARG;
+    if (d->C2 && ((reinterpret_cast<uintptr_t>(d->C2) & 15u) || d->ldc2 % 4 != 0)) return PT_ERR_ALIGN;
   }
   // reduction extent must be whole 16-byte chunks when it lies along operand columns
   GemmParams p;
@@ -349,6 +364,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.conv_wgrad_cin = d->conv_wgrad_cin;
   p.conv_wgrad_cin_store = d->conv_wgrad_cin_store > 0 ? d->conv_wgrad_cin_store : d->conv_wgrad_cin;
   p.alpha = d->alpha;
+  p.act = d->act; p.act2 = d->act2; p.C2 = reinterpret_cast<char*>(d->C2); p.ldc2 = d->ldc2;
   p.tiles_m = (int)((d->M + BM - 1) / BM); p.tiles_n = (int)((d->N + BN - 1) / BN);
   if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

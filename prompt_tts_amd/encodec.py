@@ -1,0 +1,169 @@
+"""Encodec 24 kHz code -> waveform decoder on the HIP kernels (reference: decode_codec.py:8-16).
+
+Token-major activations; the transposed convs are plain GEMMs whose N = r*Cout output columns ARE the r new
+time steps (zero-copy upsampling), the residual block's 1x1 conv and 1x1 shortcut are fused into one concat-K
+GEMM, ELUs live in epilogues (or on fragment load), the 24 kHz end (<= 64 channels) runs on the row-streaming
+kernel, the LSTM recurrence on T+1 dependent launches issued from inside the library.
+Weights are a flat dict of EFFECTIVE tensors (weight-norm folded at load time; names in `WEIGHT_KEYS`).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from ._lib import lib, check
+
+RATIOS = (8, 5, 4, 2)
+WEIGHT_KEYS = ["codebooks", "conv0.w", "conv0.b"] + [f"lstm.{n}{l}" for l in range(2) for n in ("w_ih", "w_hh", "b_ih", "b_hh")] + \
+    [f"{p}{i}.{s}" for i in range(4) for p, s in (("up", "w"), ("up", "b"))] + \
+    [f"res{i}.{c}.{s}" for i in range(4) for c in ("c3", "c1", "sc") for s in ("w", "b")] + ["final.w", "final.b"]
+
+
+def fold_weight_norm(g, v, dim=0):
+    """w = g * v / ||v|| (norm over all dims but `dim`), the fold of torch.nn.utils.weight_norm."""
+    dims = [d for d in range(v.dim()) if d != dim]
+    return g * v / v.norm(2, dim=dims, keepdim=True)
+
+
+def weights_from_encodec_state_dict(sd, n_q=8):
+    """Map an `encodec.EncodecModel.state_dict()` (original package naming, weight_g/weight_v) to effective weights."""
+    def conv(prefix, dim=0):
+        return fold_weight_norm(sd[prefix + ".weight_g"], sd[prefix + ".weight_v"], dim), sd[prefix + ".bias"]
+    W = {"codebooks": torch.stack([sd[f"quantizer.vq.layers.{q}._codebook.embed"] for q in range(n_q)])}
+    W["conv0.w"], W["conv0.b"] = conv("decoder.model.0.conv.conv")
+    for l in range(2):
+        for n, k in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
+            W[f"lstm.{n}{l}"] = sd[f"decoder.model.1.lstm.{k}_l{l}"]
+    idx = 3
+    for i in range(4):
+        W[f"up{i}.w"], W[f"up{i}.b"] = conv(f"decoder.model.{idx}.convtr.convtr")
+        rb = f"decoder.model.{idx + 1}"
+        W[f"res{i}.c3.w"], W[f"res{i}.c3.b"] = conv(rb + ".block.1.conv.conv")
+        W[f"res{i}.c1.w"], W[f"res{i}.c1.b"] = conv(rb + ".block.3.conv.conv")
+        W[f"res{i}.sc.w"], W[f"res{i}.sc.b"] = conv(rb + ".shortcut.conv.conv")
+        idx += 3
+    W["final.w"], W["final.b"] = conv(f"decoder.model.{idx}.conv.conv")
+    return W
+
+
+def _conv_mat(w):
+    """Conv1d (Cout,Cin,k) -> [Cout][k*Cin] with column = tap*Cin + ci."""
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def _pad_cols(m, mult):
+    k = m.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return m.contiguous()
+    out = torch.zeros(m.shape[0], kp, dtype=m.dtype)
+    out[:, :k] = m
+    return out
+
+
+class EncodecDecoder:
+    sample_rate = 24000
+
+    def __init__(self, weights, device="cuda", dtype=torch.bfloat16):
+        missing = [k for k in WEIGHT_KEYS if k not in weights]
+        if missing:
+            raise KeyError(f"missing decoder weights: {missing[:4]}...")
+        self.device, self.dtype, self.pt = torch.device(device), dtype, ops._DT[dtype]
+        W = {k: v.detach().float().cpu() for k, v in weights.items()}
+        d = lambda t: t.to(self.device, dtype).contiguous()
+        f = lambda t: t.to(self.device, torch.float32).contiguous()
+        self.n_q = W["codebooks"].shape[0]
+        self.codebooks = d(W["codebooks"])
+        self.w0, self.b0 = d(_conv_mat(W["conv0.w"])), f(W["conv0.b"])
+        self.w_ih0 = d(W["lstm.w_ih0"]); self.bias0 = f(W["lstm.b_ih0"] + W["lstm.b_hh0"])
+        self.w_hh0 = d(W["lstm.w_hh0"])
+        self.wcat1 = d(torch.cat([W["lstm.w_ih1"], W["lstm.w_hh1"]], dim=1)); self.bias1 = f(W["lstm.b_ih1"] + W["lstm.b_hh1"])
+        self.stages = []
+        Cc = 512
+        for i, r in enumerate(RATIOS):
+            wt = W[f"up{i}.w"]                                            # (Cin, Cout, 2r)
+            cin, cout = wt.shape[0], wt.shape[1]
+            # Wt[rho*Cout + co][tap*Cin + ci] = w[ci][co][rho + tap*r]
+            m = wt.view(cin, cout, 2, r).permute(3, 1, 2, 0).reshape(r * cout, 2 * cin)
+            c3 = _conv_mat(W[f"res{i}.c3.w"])
+            fused = torch.cat([W[f"res{i}.c1.w"][:, :, 0], W[f"res{i}.sc.w"][:, :, 0]], dim=1)
+            small = cout <= 64                 # residual block on the row-streaming kernel
+            small_up = r * cout <= 64          # transposed conv on the row-streaming kernel
+            self.stages.append(dict(
+                r=r, cin=cin, cout=cout, small=small, small_up=small_up,
+                wt=d(_pad_cols(m, 32) if small_up else m), bt=f(W[f"up{i}.b"].repeat(r)),
+                w3=d(_pad_cols(c3, 32) if small else c3), b3=f(W[f"res{i}.c3.b"]),
+                wf=d(_pad_cols(fused, 32) if small else fused), bf=f(W[f"res{i}.c1.b"] + W[f"res{i}.sc.b"])))
+            Cc = cout
+        self.wfin, self.bfin = d(_pad_cols(_conv_mat(W["final.w"]), 32)), f(W["final.b"])
+
+    # -- helpers --------------------------------------------------------------------------------------------------
+    def _rowconv(self, Bn, n_rows, x, cin, taps, rowmap, w, bias, N, y, act=0, elu_x=0, x2=None, cin2=0, elu_x2=0, y_f32=False):
+        d = L.pt_rowconv_desc()
+        d.B, d.n_rows = Bn, n_rows
+        d.x, d.ldx, d.cin, d.taps, d.rowmap, d.elu_x = x.data_ptr(), x.stride(0), cin, taps, rowmap, elu_x
+        if x2 is not None:
+            d.x2, d.ldx2, d.cin2, d.elu_x2 = x2.data_ptr(), x2.stride(0), cin2, elu_x2
+        d.w, d.ldw, d.bias, d.N, d.act = w.data_ptr(), w.stride(0), bias.data_ptr(), N, act
+        d.y, d.ldy, d.y_f32 = y.data_ptr(), y.stride(0), int(y_f32)
+        check(lib.pt_rowconv(C.byref(d), self.pt, ops._stream()), "pt_rowconv")
+
+    def _empty(self, rows, cols, dtype=None):
+        return torch.empty(rows, cols, dtype=dtype or self.dtype, device=self.device)
+
+    # -- decode -----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, codes):
+        """codes (B, n_q, T) int64 in [0,1023] -> wav (B, 1, 320*T) f32."""
+        if codes.dim() != 3:
+            raise BaseException("The encoded_frames must have the shape of [B, N_q, T]")
+        if codes.shape[1] != self.n_q:
+            raise ValueError(f"expected {self.n_q} codebooks, got {codes.shape[1]}")
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, n_q, T = codes.shape
+        if T < 7:
+            raise ValueError("the causal reflect padding of the k=7 convs needs at least 7 frames")
+        pt, M = self.pt, B * T
+        e0 = self._empty(M, 128)
+        check(lib.pt_rvq_decode(codes.data_ptr(), self.codebooks.data_ptr(), e0.data_ptr(), B, n_q, T, 1024, 128, pt,
+                                ops._stream()), "pt_rvq_decode")
+        y0 = self._empty(M, 512)
+        ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0), y0, pt, bias=self.b0)
+        xg0 = self._empty(M, 2048)
+        ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
+        h0 = self._empty(M, 512); h1 = self._empty(M, 512); ze = self._empty(M, 512)
+        c0 = torch.empty(B, 512, dtype=torch.float32, device=self.device); c1 = torch.empty_like(c0)
+        ld = L.pt_lstm2_desc()
+        ld.B, ld.T, ld.H = B, T, 512
+        ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = y0.data_ptr(), xg0.data_ptr(), self.w_hh0.data_ptr(), self.wcat1.data_ptr(), self.bias1.data_ptr()
+        ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
+        check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
+        xe, n = ze, T                     # xe = ELU(stage input), n = rows per batch item
+        for st in self.stages:
+            r, cin, cout = st["r"], st["cin"], st["cout"]
+            Min, Mout, n_out = B * n, B * n * r, n * r
+            x1 = self._empty(Min, r * cout)
+            x1e = None
+            if st["small_up"]:
+                self._rowconv(B, n, xe, cin, 2, L.PT_MAP_BACK, st["wt"], st["bt"], r * cout, x1)
+            else:
+                x1e = self._empty(Min, r * cout)
+                ops.gemm(Min, r * cout, 2 * cin, ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2), ops.plain(st["wt"]), x1, pt,
+                         bias=st["bt"], out2=x1e, ldc2=r * cout, act2=1)
+            x1v = x1.view(Mout, cout)
+            c3e = self._empty(Mout, cout // 2)
+            oute = self._empty(Mout, cout)
+            if st["small"]:
+                src, elu = (x1e.view(Mout, cout), 0) if x1e is not None else (x1v, 1)
+                self._rowconv(B, n_out, src, cout, 3, L.PT_MAP_CAUSAL_REFLECT, st["w3"], st["b3"], cout // 2, c3e, act=1, elu_x=elu)
+                self._rowconv(B, n_out, c3e, cout // 2, 1, L.PT_MAP_BACK, st["wf"], st["bf"], cout, oute, act=1,
+                              x2=x1v, cin2=cout)
+            else:
+                ops.gemm(Mout, cout // 2, 3 * cout, ops.conv(x1e.view(Mout, cout), cout, n_out, n_out, L.PT_MAP_CAUSAL_REFLECT, taps=3),
+                         ops.plain(st["w3"]), c3e, pt, bias=st["b3"], act=1)
+                ops.gemm(Mout, cout, cout // 2 + cout, ops.concat(c3e, x1v), ops.plain(st["wf"]), oute, pt, bias=st["bf"], act=1)
+            xe, n = oute, n_out
+        wav = torch.empty(B * n, 1, dtype=torch.float32, device=self.device)
+        self._rowconv(B, n, xe, 32, 7, L.PT_MAP_CAUSAL_REFLECT, self.wfin, self.bfin, 1, wav, y_f32=True)
+        return wav.view(B, 1, n)

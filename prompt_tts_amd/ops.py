@@ -66,7 +66,8 @@ def wflip(w3, cout, cin_pad, trans=True):
 
 
 def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bias=None, row_bias=None,
-         row_bias_rows=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0):
+         row_bias_rows=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0,
+         act=0, out2=None, ldc2=0, act2=0):
     d = L.pt_gemm_desc()
     d.M, d.N, d.K = M, N, K
     d.A, d.B = A, B
@@ -77,6 +78,7 @@ def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bi
     d.residual2 = _p(residual2); d.ldr2 = ldr2
     d.conv_wgrad_cin = conv_wgrad_cin; d.conv_wgrad_cin_store = conv_wgrad_cin_store
     d.alpha = alpha
+    d.act = act; d.act2 = act2; d.C2 = _p(out2); d.ldc2 = ldc2
     check(lib.pt_gemm(C.byref(d), dtype, _stream()), "pt_gemm")
 
 

@@ -77,7 +77,7 @@ def test_cabi_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (pt_\w+)", out))
     assert exported >= declared
-    assert _lib.lib.pt_abi_version() >= 2
+    assert _lib.lib.pt_abi_version() >= 3
     assert b"aligned" in _lib.lib.pt_status_string(-4)
     # argument validation returns before any HIP call: safe without a GPU
     assert _lib.lib.pt_gemm(None, 1, None) == -5
@@ -85,7 +85,7 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.pt_gemm(ctypes.byref(d), 1, None) == -1
     assert _lib.lib.pt_gemm(ctypes.byref(d), 7, None) == -2
     assert _lib.lib.pt_attn_fwd(None, 1, None) == -5
-    for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg)):
+    for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg, _lib.pt_rowconv_desc, _lib.pt_lstm2_desc)):
         assert _lib.lib.pt_struct_size(i) == ctypes.sizeof(st)          # the ctypes mirror matches the C layout
 
 
