@@ -3,7 +3,11 @@
 // staging): the LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the per-lane
 // SOURCE address (and again on the fragment read); chunks that must read as zero (conv padding, M/N/K tails)
 // point at a zero page.  Two LDS stages: the loads of k-tile t+1 are in flight under the MFMAs of k-tile t,
-// one barrier per k-tile; 64 KiB LDS and <= 256 registers keep two workgroups resident per CU.
+// one barrier per k-tile; 72 KiB LDS and <= 256 registers keep two workgroups resident per CU, so one workgroup's
+// prologue/epilogue overlaps the other's main loop (most GEMMs here have K = 512 = 8 k-tiles).
+// Measured with tools/gemm_probe.py: address generation (not memory) bounded the staging path and 8-byte scattered
+// stores the epilogue; hence per-chunk source pointers advanced by a byte step (recomputed only at segment
+// boundaries: new conv tap, concat half, K tail) and an LDS-transposed epilogue that stores whole 128-byte rows.
 //
 // Operands are "virtual matrices" (include/prompt_tts_hip.h): plain, channel-concat, conv-gather (implicit
 // GEMM for Conv1d k=3 stride 1/2, upsample+conv, and their dgrad/wgrad) and flipped conv weights; each is
@@ -14,6 +18,10 @@
 // Roofline: MFMA-bound for K >= 512 (2*128*128*K flops per 2*128*K*sizeof(T) operand bytes per tile).
 #include "mma.h"
 
+#ifndef PT_GEMM_ABLATE
+#define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores
+#endif
+
 namespace {
 
 struct VOp {
@@ -22,6 +30,8 @@ struct VOp {
   int kind, taps, cin, rowmap;
   int n_out, n_in;
   int cin_shift, nout_shift;   // log2 when a power of two, else -1
+  int seg_kt;                  // k-tiles over which a chunk's address advances by `step` bytes per k-tile (1: recompute always)
+  int64_t step;                // bytes per k-tile inside a segment
   int64_t rows, cols;   // logical extent of the virtual matrix
 };
 
@@ -87,13 +97,14 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
 
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 16384;   // one operand tile image
+constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
 
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
   constexpr int TCH = 128 / EPC;                   // chunks per TileT row (128 columns)
-  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES + 4 * SCRATCH_PER_WAVE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -125,35 +136,65 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
   // data chunk (q%TCH)^swz(k): the swizzle lives in the SOURCE address.
   const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
-  auto stage = [&](int kt, int stg) {
+  // Per-chunk source pointers live in registers and advance by a per-operand byte step; they are recomputed from
+  // scratch (vaddr) only at segment boundaries, tracked with down-counters (no division in the loop).
+  const char* pa[4]; const char* pb[4];
+  const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
+  const int last_kt = nkt_total - 1;
+  const bool ktail = (p.K % BK) != 0;
+  int a_left = p.A.seg_kt - kt_begin % p.A.seg_kt, b_left = p.B.seg_kt - kt_begin % p.B.seg_kt;
+  auto stage = [&](int kt, int stg, bool fresh) {
     const int64_t k0 = (int64_t)kt * BK;
     char* sa = smem + stg * 2 * STAGE_BYTES;
     char* sb = sa + STAGE_BYTES;
+    const bool tail = ktail && kt == last_kt;
+    bool slow_a = fresh || tail, slow_b = fresh || tail;
+    if (!fresh) {
+      if (--a_left == 0) { slow_a = true; a_left = p.A.seg_kt; }
+      if (--b_left == 0) { slow_b = true; b_left = p.B.seg_kt; }
+    }
+    if (slow_a) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCH; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[i] = (pa[i] == zero_page) ? zero_page : pa[i] + p.A.step;
+    }
+    if (slow_b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCH; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pb[i] = (pb[i] == zero_page) ? zero_page : pb[i] + p.B.step;
+    }
+    if (PT_GEMM_ABLATE == 2) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int q = tid + 256 * i;
-      const char* ga; const char* gb;
-      if (!TA) { const int r = q >> 3; ga = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-      else     { const int k = q / TCH; ga = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
-      if (!TB) { const int r = q >> 3; gb = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-      else     { const int k = q / TCH; gb = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
       const int lds_off = (wbase + 256 * i) * 16;
-      __builtin_amdgcn_global_load_lds((pt_gptr*)ga, (pt_lptr*)(sa + lds_off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((pt_gptr*)gb, (pt_lptr*)(sb + lds_off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + lds_off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + lds_off), 16, 0, 0);
     }
   };
 
-  stage(kt_begin, 0);
+  stage(kt_begin, 0, true);
   __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = kt + 1 < kt_end;
-    if (more) stage(kt + 1, cur ^ 1);
+    if (more) stage(kt + 1, cur ^ 1, false);
     const char* sa = smem + cur * 2 * STAGE_BYTES;
     const char* sb = sa + STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
+    for (int ks = 0; ks < (PT_GEMM_ABLATE == 1 ? 0 : BK / 32); ++ks) {
       Frag<T> fa[4], fb[4];
       const int kb = ks * 32 + 8 * g;
 #pragma unroll
@@ -204,63 +245,102 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       }
     return;
   }
+  // Phase 1 (accumulator layout: lane = row li, 4 consecutive columns per register group): alpha, bias, row bias,
+  // residuals (vector loads).  Phase 2: activation + conversion, then the wave's 16 x 64 (bf16) / 16 x 32 (f32)
+  // sub-tile goes through a wave-private XOR-swizzled LDS scratch and leaves as whole row segments, 16 B per lane.
+  const bool out32 = sizeof(T) == 4 || p.out_kind == PT_OUT_F32;
+  char* scratch = smem + 4 * STAGE_BYTES + wave * SCRATCH_PER_WAVE;
+  const int n_outs = p.C2 ? 2 : 1;
+  const int64_t mrow0 = (PT_GEMM_ABLATE == 3) ? ((int64_t)1 << 40) : m0 + wm * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + 16 * i + li;
-    if (m >= p.M) continue;
-    const float* rbias = p.row_bias ? p.row_bias + (m / p.row_bias_rows) * p.N : nullptr;
+    const int64_t m = mrow0 + 16 * i + li;
+    const bool mok = m < p.M;
+    const float* rbias = (p.row_bias && mok) ? p.row_bias + (m / p.row_bias_rows) * p.N : nullptr;
+    float v[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t n = n0 + wn * 64 + 16 * j + 4 * g;
-      if (n >= p.N) continue;
-      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r];
-      const bool full = n + 3 < p.N;
-      if (full) {
-        if (p.bias) { f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
-        if (rbias) { f32x4_t b = *reinterpret_cast<const f32x4_t*>(rbias + n); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+      for (int r = 0; r < 4; ++r) v[j][r] = p.alpha * acc[i][j][r];
+      if (mok && n + 3 < p.N) {
+        if (p.bias) { const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.bias + n); v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3]; }
+        if (rbias) { const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rbias + n); v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3]; }
         if (p.residual) {
           const T* rp = reinterpret_cast<const T*>(p.residual) + m * p.ldr + n;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          for (int r = 0; r < 4; ++r) v[j][r] += to_f32<T>(rp[r]);
         }
         if (p.residual2) {
           const T* rp = reinterpret_cast<const T*>(p.residual2) + m * p.ldr2 + n;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          for (int r = 0; r < 4; ++r) v[j][r] += to_f32<T>(rp[r]);
         }
-        auto put = [&](char* base, int64_t ld, int act) {
+      } else if (mok) {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          if (p.bias) v[j][r] += p.bias[n + r];
+          if (rbias) v[j][r] += rbias[n + r];
+          if (p.residual) v[j][r] += to_f32<T>(reinterpret_cast<const T*>(p.residual)[m * p.ldr + n + r]);
+          if (p.residual2) v[j][r] += to_f32<T>(reinterpret_cast<const T*>(p.residual2)[m * p.ldr2 + n + r]);
+        }
+      }
+    }
+    for (int op = 0; op < n_outs; ++op) {
+      char* Cb = op == 0 ? p.C : p.C2;
+      const int64_t ld = op == 0 ? p.ldc : p.ldc2;
+      const int act = op == 0 ? p.act : p.act2;
+      if (!out32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           float w[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[r] < 0.f) ? (__expf(v[r]) - 1.f) : v[r];
-          if (p.out_kind == PT_OUT_F32) {
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(base) + m * ld + n) = (f32x4_t){w[0], w[1], w[2], w[3]};
-          } else if (sizeof(T) == 4) {
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(base) + m * ld + n) = (f32x4_t){w[0], w[1], w[2], w[3]};
-          } else {
-            u32x2_t o;
-            o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
-            *reinterpret_cast<u32x2_t*>(reinterpret_cast<T*>(base) + m * ld + n) = o;
+          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
+          u32x2_t o;
+          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          const int chunk = 2 * j + (g >> 1);
+          *reinterpret_cast<u32x2_t*>(scratch + li * 128 + ((chunk ^ (li & 7)) << 4) + ((g & 1) << 3)) = o;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = 8 * it + (lane >> 3), c = lane & 7;
+          const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
+          const int64_t mm = mrow0 + 16 * i + r, nn = n0 + wn * 64 + 8 * c;
+          if (mm < p.M && nn < p.N) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + mm * ld + nn;
+            if (nn + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+              *reinterpret_cast<u32x4_t*>(dst) = val;
+            } else {
+              for (int e = 0; e < 8 && nn + e < p.N; ++e) {
+                const uint32_t wv = val[e >> 1];
+                bf16_t h; h.bits = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+                dst[e] = h;
+              }
+            }
           }
-        };
-        put(p.C, p.ldc, p.act);
-        if (p.C2) put(p.C2, p.ldc2, p.act2);
+        }
       } else {
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-          float x = v[r];
-          if (p.bias) x += p.bias[n + r];
-          if (rbias) x += rbias[n + r];
-          if (p.residual) x += to_f32<T>(reinterpret_cast<const T*>(p.residual)[m * p.ldr + n + r]);
-          if (p.residual2) x += to_f32<T>(reinterpret_cast<const T*>(p.residual2)[m * p.ldr2 + n + r]);
-          const float x1 = (p.act == 1 && x < 0.f) ? (__expf(x) - 1.f) : x;
-          if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C)[m * p.ldc + n + r] = x1;
-          else reinterpret_cast<T*>(p.C)[m * p.ldc + n + r] = from_f32<T>(x1);
-          if (p.C2) {
-            const float x2 = (p.act2 == 1 && x < 0.f) ? (__expf(x) - 1.f) : x;
-            if (p.out_kind == PT_OUT_F32) reinterpret_cast<float*>(p.C2)[m * p.ldc2 + n + r] = x2;
-            else reinterpret_cast<T*>(p.C2)[m * p.ldc2 + n + r] = from_f32<T>(x2);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * half + jj;
+            f32x4_t w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
+            const int chunk = 4 * jj + g;
+            *reinterpret_cast<f32x4_t*>(scratch + li * 128 + ((chunk ^ (li & 7)) << 4)) = w;
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = 8 * it + (lane >> 3), c = lane & 7;
+            const f32x4_t val = *reinterpret_cast<const f32x4_t*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
+            const int64_t mm = mrow0 + 16 * i + r, nn = n0 + wn * 64 + 32 * half + 4 * c;
+            if (mm < p.M && nn < p.N) {
+              float* dst = reinterpret_cast<float*>(Cb) + mm * ld + nn;
+              if (nn + 3 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) *reinterpret_cast<f32x4_t*>(dst) = val;
+              else for (int e = 0; e < 4 && nn + e < p.N; ++e) dst[e] = val[e];
+            }
           }
         }
       }
@@ -268,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
-VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols) {
+VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
   VOp v;
   v.p = reinterpret_cast<const char*>(o.p); v.p2 = reinterpret_cast<const char*>(o.p2);
   v.ld = o.ld; v.ld2 = o.ld2; v.c_split = o.c_split;
@@ -277,6 +357,19 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols) {
   auto lg = [](int x) { return (x > 0 && (x & (x - 1)) == 0) ? __builtin_ctz(x) : -1; };
   v.cin_shift = lg(v.cin); v.nout_shift = lg(v.n_out);
   v.rows = rows; v.cols = cols;
+  // segment / step of the incremental addressing (see stage()): bk elements per k-tile
+  const int bk = 128 / es;
+  v.seg_kt = 1; v.step = 0;
+  if (!o.trans) {                               // reduction along columns
+    v.step = (int64_t)bk * es;
+    if (o.kind == PT_V_PLAIN) v.seg_kt = 1 << 30;
+    else if (o.kind == PT_V_CONCAT) v.seg_kt = (o.c_split % bk == 0) ? (int)(o.c_split / bk) : 1;
+    else if (o.kind == PT_V_CONV) v.seg_kt = (v.cin % bk == 0) ? v.cin / bk : 1;
+  } else {                                      // reduction along rows
+    if (o.kind == PT_V_PLAIN) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
+    else if (o.kind == PT_V_CONCAT && o.ld == o.ld2) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
+    else if (o.kind == PT_V_WFLIP && v.cin % bk == 0) { v.seg_kt = v.cin / bk; v.step = (int64_t)bk * 3 * o.ld * es; }
+  }
   return v;
 }
 
@@ -354,8 +447,8 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   // reduction extent must be whole 16-byte chunks when it lies along operand columns
   GemmParams p;
   p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A.trans ? make_vop(d->A, d->K, d->M) : make_vop(d->A, d->M, d->K);
-  p.B = d->B.trans ? make_vop(d->B, d->K, d->N) : make_vop(d->B, d->N, d->K);
+  p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
+  p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
   p.C = reinterpret_cast<char*>(d->C); p.ldc = d->ldc;
   p.out_kind = d->out_kind; p.split_k = d->split_k;
   p.bias = d->bias; p.row_bias = d->row_bias; p.row_bias_rows = d->row_bias_rows;

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Ablation probe for the GEMM kernel (run on the GPU box): builds variants of gemm.hip with parts of the kernel
+compiled out and times representative shapes of the training step.  Diagnostic only; never imported by the product."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from prompt_tts_amd import _lib as L   # noqa: E402  (struct definitions)
+
+SRC = os.path.join(ROOT, "prompt_tts_amd", "csrc")
+SHAPES = [("lin K512 N512", 32768, 512, 512), ("lin K512 N1536", 32768, 1536, 512), ("ff1 K512 N4096", 32768, 4096, 512),
+          ("ff2 K2048 N512", 32768, 512, 2048), ("conv K1536 N512", 32768, 512, 1536)]
+
+
+def build(ablate):
+    out = f"/tmp/libgemm_ab{ablate}.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                    f"-DPT_GEMM_ABLATE={ablate}", os.path.join(SRC, "gemm.hip"), "-o", out], check=True)
+    lib = C.CDLL(out)
+    lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]
+    lib.pt_gemm.restype = C.c_int
+    return lib
+
+
+def run(lib, M, N, K, iters=30):
+    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    d = L.pt_gemm_desc(); d.M, d.N, d.K = M, N, K
+    d.A.p, d.A.ld = a.data_ptr(), K; d.B.p, d.B.ld = w.data_ptr(), K
+    d.C, d.ldc, d.split_k, d.alpha = c.data_ptr(), N, 1, 1.0
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        assert lib.pt_gemm(C.byref(d), 1, st) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.pt_gemm(C.byref(d), 1, st)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+if __name__ == "__main__":
+    variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]
+    libs = {v: build(v) for v in variants}
+    print("shape".ljust(18) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
+    for name, M, N, K in SHAPES:
+        row = name.ljust(18)
+        for v in variants:
+            us = run(libs[v], M, N, K)
+            row += f"{us:9.1f}/{2.0 * M * N * K / us / 1e6:6.0f}".rjust(18)
+        print(row, flush=True)
