@@ -80,6 +80,7 @@ typedef struct pt_gemm_desc {
   const float* bias;             /* [N] or NULL                                                   */
   const float* row_bias;         /* [M / row_bias_rows][N] f32 (time-embedding add) or NULL       */
   int64_t row_bias_rows;
+  int64_t row_bias_ld;           /* stride between row_bias rows (0: N) -- lets it be a column slice of a wider matrix */
   const void* residual; int64_t ldr;   /* same dtype as activations, or NULL                      */
   const void* residual2; int64_t ldr2; /* second addend (may alias C: in-place accumulation)      */
   int32_t conv_wgrad_cin;        /* > 0: C index (m, n=tap*cin+ci) -> m*3*cin + ci*3 + tap (reference Conv1d weight layout) */
@@ -160,7 +161,8 @@ int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, int dtype, 
 /* out[(m / seg_rows)][n] += sum over the rows m of each segment of dy[m][n]  (f32 atomics); seg_rows divides M.
  * seg_rows = M gives the bias gradient; seg_rows = rows per batch item gives the time-embedding gradient.
  * N need not be a multiple of the 16-byte chunk as long as ld is (pad columns are read, never written). */
-int pt_colsum(const void* dy, int64_t ld, float* out, int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream);
+int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out /* stride between segments in out; 0: N */,
+              int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream);
 
 /* word_embedding(ids) + positional table (tts/models.py:112-115): out[b][s][:] = W[ids[b][s]][:] + pos[s][:]. */
 int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out,

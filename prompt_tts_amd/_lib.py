@@ -25,7 +25,7 @@ class pt_operand(C.Structure):
 class pt_gemm_desc(C.Structure):
     _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("A", pt_operand), ("B", pt_operand),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("out_kind", C.c_int32), ("split_k", C.c_int32),
-                ("bias", C.c_void_p), ("row_bias", C.c_void_p), ("row_bias_rows", C.c_int64),
+                ("bias", C.c_void_p), ("row_bias", C.c_void_p), ("row_bias_rows", C.c_int64), ("row_bias_ld", C.c_int64),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("residual2", C.c_void_p), ("ldr2", C.c_int64),
                 ("conv_wgrad_cin", C.c_int32),
                 ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
@@ -80,7 +80,7 @@ SIGNATURES = {
     "pt_silu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_add": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_pairsum_rows": [_vp, _vp, _i64, _i64, _i32, _vp],
-    "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_embedding_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_embedding_bwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pt_timestep_embedding": [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp],

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT) void pairsum_kernel(const T* __restrict__ x, T*
 
 // out[seg][n] += sum over the segment's rows of dy[m][n]: block = run of rows inside ONE segment, thread = fixed chunk
 template <typename T>
-__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out, int64_t ld_out,
                                                     int64_t seg_rows, int N, int rows_per_block) {
   constexpr int EPC = Vec16<T>::N;
   const int CC = (N + EPC - 1) / EPC;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, in
       float acc[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll 8
       for (int64_t r = s0 + rr; r < s1; r += RP) {
         Vec16<T> v = load16(dy + (seg * seg_rows + r) * ld + (int64_t)c * EPC);
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, in
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += NT) unsafeAtomicAdd(out + seg * N + i, sh[i]);
+  for (int i = threadIdx.x; i < N; i += NT) unsafeAtomicAdd(out + seg * ld_out + i, sh[i]);
 }
 
 // ---- embedding ---------------------------------------------------------------------------------------
@@ -285,18 +286,19 @@ extern "C" int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, 
               hipLaunchKernelGGL((pairsum_kernel<bf16_t>), dim3(grid_for(rows * C / 8)), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
 }
 
-extern "C" int pt_colsum(const void* dy, int64_t ld, float* out, int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream) {
+extern "C" int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out, int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream) {
+  if (ld_out <= 0) ld_out = N;
   if (M <= 0 || N <= 0 || N > 16384 || seg_rows <= 0 || M % seg_rows != 0 || M / seg_rows > 65535) return PT_ERR_SHAPE;
   const int es = dtype == PT_F32 ? 4 : 2, epc = 16 / es;
   if (!pt_aligned16(dy) || (ld * es) % 16 != 0) return PT_ERR_ALIGN;
   if (ld < (N + epc - 1) / epc * epc) return PT_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = 128;
+  const int rpb = 64;
   dim3 grid((unsigned)((seg_rows + rpb - 1) / rpb), (unsigned)(M / seg_rows));
   const size_t dyn = sizeof(float) * (size_t)((N + epc - 1) / epc * epc);
   PT_DISPATCH(dtype,
-              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(NT), dyn, s, (const float*)dy, ld, out, seg_rows, (int)N, rpb),
-              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(NT), dyn, s, (const bf16_t*)dy, ld, out, seg_rows, (int)N, rpb));
+              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(NT), dyn, s, (const float*)dy, ld, out, ld_out, seg_rows, (int)N, rpb),
+              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(NT), dyn, s, (const bf16_t*)dy, ld, out, ld_out, seg_rows, (int)N, rpb));
 }
 
 extern "C" int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out, int64_t BS, int64_t S,

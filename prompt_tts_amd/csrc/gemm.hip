@@ -40,7 +40,7 @@ struct GemmParams {
   int64_t M, N, K;
   char* C; int64_t ldc;
   int out_kind, split_k;
-  const float* bias; const float* row_bias; int64_t row_bias_rows;
+  const float* bias; const float* row_bias; int64_t row_bias_rows, row_bias_ld;
   const char* residual; int64_t ldr;
   const char* residual2; int64_t ldr2;
   int conv_wgrad_cin, conv_wgrad_cin_store;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   for (int i = 0; i < 4; ++i) {
     const int64_t m = mrow0 + 16 * i + li;
     const bool mok = m < p.M;
-    const float* rbias = (p.row_bias && mok) ? p.row_bias + (m / p.row_bias_rows) * p.N : nullptr;
+    const float* rbias = (p.row_bias && mok) ? p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld : nullptr;
     float v[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -440,7 +440,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
     const int oes = d->out_kind == PT_OUT_F32 ? 4 : es;
     if ((reinterpret_cast<uintptr_t>(d->C) & 15u) || (d->ldc * oes) % (4 * oes) != 0) return PT_ERR_ALIGN;
     if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15u)) return PT_ERR_ALIGN;
-    if (d->row_bias && ((reinterpret_cast<uintptr_t>(d->row_bias) & 15u) || d->row_bias_rows <= 0 || (d->N % 4))) return PT_ERR_ALIGN;
+    if (d->row_bias && ((reinterpret_cast<uintptr_t>(d->row_bias) & 15u) || d->row_bias_rows <= 0 || (d->N % 4) || (d->row_bias_ld % 4))) return PT_ERR_ALIGN;
     if (d->conv_wgrad_cin > 0) return PT_ERR_ARG;
     if (d->C2 && ((reinterpret_cast<uintptr_t>(d->C2) & 15u) || d->ldc2 % 4 != 0)) return PT_ERR_ALIGN;
   }
@@ -451,7 +451,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
   p.C = reinterpret_cast<char*>(d->C); p.ldc = d->ldc;
   p.out_kind = d->out_kind; p.split_k = d->split_k;
-  p.bias = d->bias; p.row_bias = d->row_bias; p.row_bias_rows = d->row_bias_rows;
+  p.bias = d->bias; p.row_bias = d->row_bias; p.row_bias_rows = d->row_bias_rows; p.row_bias_ld = d->row_bias_ld > 0 ? d->row_bias_ld : d->N;
   p.residual = reinterpret_cast<const char*>(d->residual); p.ldr = d->ldr;
   p.residual2 = reinterpret_cast<const char*>(d->residual2); p.ldr2 = d->ldr2;
   p.conv_wgrad_cin = d->conv_wgrad_cin;

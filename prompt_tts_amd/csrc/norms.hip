@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x1, 
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s[j][e] = 0.f; ss[j][e] = 0.f; }
   if (rr < g.RP) {
+#pragma unroll 4
     for (int r = r0 + rr; r < r1; r += g.RP) {
       const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x1, 
       }
     }
   }
+#pragma unroll 4
   for (int r = r0 + rr; r < r1; r += g.RP) {
     const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ d
     }
   }
   if (rr < g.RP) {
+#pragma unroll 4
     for (int r = r0 + rr; r < r1; r += g.RP) {
       const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
       }
     }
   }
+#pragma unroll 4
   for (int r = r0 + rr; r < r1; r += g.RP) {
     const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll

@@ -40,11 +40,16 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
     const float nrm = sqrtf(*gnorm_sq);
     clip = fminf(1.f, max_norm / (nrm + 1e-6f));       // torch.nn.utils.clip_grad_norm_
   }
+  __shared__ int s_first;
   for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < n_total; base += (int64_t)gridDim.x * CHUNK) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_first = find_seg(seg, n_seg, base);     // one binary search per 4096-element chunk
+    __syncthreads();
     for (int k = threadIdx.x; k < CHUNK; k += NT) {
       const int64_t i = base + k;
       if (i >= n_total) break;
-      const int si = find_seg(seg, n_seg, i);
+      int si = s_first;
+      while (si + 1 < n_seg && seg[si + 1].offset <= i) ++si;       // tensors are mostly larger than a chunk: 0-1 steps
       const pt_param_seg sg = seg[si];
       const int64_t local = i - sg.offset;
       if (local >= sg.numel) continue;                 // alignment padding between tensors

@@ -33,8 +33,18 @@ class ParamStore:
         self.names, self.params, self.info = [], [], {}
         off = soff = 0
         segs = []
-        for name, p in module.named_parameters():
+        # Every ResnetBlock1D.time_emb_proj is packed, in forward order, into ONE contiguous "late" region at the end of
+        # the flat buffers (weights, then biases), so the 2L+... per-resnet time-embedding projections of a step are a
+        # single GEMM forward and two backward instead of dozens of M = B launches.
+        named = list(module.named_parameters())
+        is_late = lambda nm: nm.endswith("time_emb_proj.weight") or nm.endswith("time_emb_proj.bias")
+        ordered = [(nm, p) for nm, p in named if not is_late(nm)] + \
+                  [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.weight")] + \
+                  [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.bias")]
+        self.late = {"w": [], "b": []}
+        for name, p in ordered:
             n = p.numel()
+            late = is_late(name)
             is_conv3 = p.dim() == 3 and p.shape[2] == 3
             frozen = name.endswith("proj_out.weight") or name.endswith("proj_out.bias")
             if is_conv3:
@@ -49,9 +59,16 @@ class ParamStore:
                 seg = (off, n, soff, 0, 0, 0, int(frozen))
                 sshape = (p.shape[0], n // p.shape[0]) if p.dim() >= 2 else (n,)
             self.names.append(name); self.params.append(p)
-            self.info[id(p)] = dict(off=off, n=n, soff=soff, sn=sn, sshape=sshape, frozen=frozen, name=name)
+            self.info[id(p)] = dict(off=off, n=n, soff=soff, sn=sn, sshape=sshape, frozen=frozen, name=name, late=late)
             segs.append(seg)
-            off += _round_up(n, ALIGN); soff += _round_up(sn, ALIGN)
+            if late:
+                if n % 4 != 0:
+                    raise ValueError("time_emb_proj tensors must be multiples of 4 elements")
+                self.late["w" if name.endswith("weight") else "b"].append(p)
+                off += n; soff += n                       # packed back to back
+            else:
+                off += _round_up(n, ALIGN); soff += _round_up(sn, ALIGN)
+        off = _round_up(off, ALIGN); soff = _round_up(soff, ALIGN)
         self.n_total, self.n_shadow, self.n_seg = off, soff, len(segs)
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
@@ -99,8 +116,20 @@ class ParamStore:
 
     def span(self, ps):
         """[lo, hi) element range of the flat buffers covering parameters ps (registration-contiguous)."""
-        infos = [self.info[id(p)] for p in ps]
+        infos = [self.info[id(p)] for p in ps if not self.info[id(p)]["late"]]
+        if not infos:
+            return 0, 0
         return min(i["off"] for i in infos), max(i["off"] + _round_up(i["n"], ALIGN) for i in infos)
+
+    def late_views(self):
+        """(W [Ct][K] f32 master, dW, b [Ct], db) over all time_emb_proj tensors, or None when there are none."""
+        if not self.late["w"]:
+            return None
+        iw, ib = self.info[id(self.late["w"][0])], self.info[id(self.late["b"][0])]
+        K = self.late["w"][0].shape[1]
+        Ct = sum(p.shape[0] for p in self.late["w"])
+        return (self.flat_p[iw["off"]:iw["off"] + Ct * K].view(Ct, K), self.flat_g[iw["off"]:iw["off"] + Ct * K].view(Ct, K),
+                self.flat_p[ib["off"]:ib["off"] + Ct], self.flat_g[ib["off"]:ib["off"] + Ct])
 
     # -- maintenance ---------------------------------------------------------------------------------------
     def attach_grads(self):
@@ -167,7 +196,9 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
     ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
              out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype))
     if gbias is not None:
-        ops.colsum(dy, gbias, M, N)
+        for c0 in range(0, N, 8192):                     # the column-sum kernel keeps its columns in LDS
+            c1 = min(N, c0 + 8192)
+            ops.colsum(dy[:, c0:c1], gbias[c0:c1], M, c1 - c0)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else (dx_accum if dx_accum is not None else _empty(M, K, x))
@@ -182,7 +213,7 @@ _ROWMAP_DGRAD = {L.PT_MAP_S1: L.PT_MAP_S1, L.PT_MAP_S2: L.PT_MAP_S2_DGRAD}
 
 
 def conv3_fwd(x, w3, bias, B, n_in, rowmap=L.PT_MAP_S1, cin=None, cout=None, row_bias=None, residual=None,
-              x2=None, out=None, ldc=None):
+              x2=None, out=None, ldc=None, row_bias_ld=0):
     """Conv1d k=3 pad=1 as implicit GEMM.  x: (B*n_in, cin) token-major; w3: shadow [cout_pad][3*cin_pad]."""
     cin = x.shape[1] if cin is None else cin
     cout = w3.shape[0] if cout is None else cout
@@ -191,7 +222,7 @@ def conv3_fwd(x, w3, bias, B, n_in, rowmap=L.PT_MAP_S1, cin=None, cout=None, row
     if out is None:
         out = _empty(M, cout, x)
     ops.gemm(M, cout, 3 * cin, ops.conv(x, cin, n_out, n_in, rowmap), ops.plain(w3), out, ops.pt_dtype(x),
-             ldc=out.stride(0) if ldc is None else ldc, bias=bias, row_bias=row_bias, row_bias_rows=n_out,
+             ldc=out.stride(0) if ldc is None else ldc, bias=bias, row_bias=row_bias, row_bias_rows=n_out, row_bias_ld=row_bias_ld,
              residual=residual, ldr=residual.stride(0) if residual is not None else 0)
     return out, n_out
 

@@ -66,14 +66,14 @@ def wflip(w3, cout, cin_pad, trans=True):
 
 
 def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bias=None, row_bias=None,
-         row_bias_rows=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0,
+         row_bias_rows=0, row_bias_ld=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0,
          act=0, out2=None, ldc2=0, act2=0):
     d = L.pt_gemm_desc()
     d.M, d.N, d.K = M, N, K
     d.A, d.B = A, B
     d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
     d.out_kind = out_kind; d.split_k = split_k
-    d.bias = _p(bias); d.row_bias = _p(row_bias); d.row_bias_rows = row_bias_rows
+    d.bias = _p(bias); d.row_bias = _p(row_bias); d.row_bias_rows = row_bias_rows; d.row_bias_ld = row_bias_ld
     d.residual = _p(residual); d.ldr = ldr
     d.residual2 = _p(residual2); d.ldr2 = ldr2
     d.conv_wgrad_cin = conv_wgrad_cin; d.conv_wgrad_cin_store = conv_wgrad_cin_store
@@ -172,10 +172,10 @@ def pairsum_rows(x, y):
     check(lib.pt_pairsum_rows(_p(x), _p(y), rows, Cc, pt_dtype(x), _stream()), "pt_pairsum_rows")
 
 
-def colsum(dy, out, M=None, N=None, seg_rows=None):
+def colsum(dy, out, M=None, N=None, seg_rows=None, ld_out=0):
     M = dy.shape[0] if M is None else M
     N = dy.shape[1] if N is None else N
-    check(lib.pt_colsum(_p(dy), dy.stride(0), _p(out), M, N, M if seg_rows is None else seg_rows, pt_dtype(dy),
+    check(lib.pt_colsum(_p(dy), dy.stride(0), _p(out), ld_out, M, N, M if seg_rows is None else seg_rows, pt_dtype(dy),
                         _stream()), "pt_colsum")
 
 

@@ -66,12 +66,13 @@ class ResnetBlock1D(nn.Module):
         self.conv2 = nn.Conv1d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv1d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
-    def fwd(self, st, x1, x2, semb, B, N):
-        """x = concat(x1, x2) (x2 None on the down path); semb = SiLU(time embedding), f32 (B, 4*C0)."""
+    def fwd(self, st, x1, x2, tproj, B, N):
+        """x = concat(x1, x2) (x2 None on the down path); tproj = this block's (B, Cout) f32 column slice of the batched
+        time-embedding projection (row stride = tproj.stride(0))."""
         Cin, Cout = self.in_channels, self.out_channels
         a1, s1 = E.groupnorm_fwd(x1, x2, st.f(self.norm1.weight), st.f(self.norm1.bias), B, N, self.groups, self.eps, True)
-        tproj = E.linear_fwd(semb, st.f(self.time_emb_proj.weight), st.f(self.time_emb_proj.bias))   # f32 (B, Cout)
-        h1, _ = E.conv3_fwd(a1, st.w(self.conv1.weight), st.f(self.conv1.bias), B, N, cin=Cin, cout=Cout, row_bias=tproj)
+        h1, _ = E.conv3_fwd(a1, st.w(self.conv1.weight), st.f(self.conv1.bias), B, N, cin=Cin, cout=Cout, row_bias=tproj,
+                            row_bias_ld=tproj.stride(0))
         a2, s2 = E.groupnorm_fwd(h1, None, st.f(self.norm2.weight), st.f(self.norm2.bias), B, N, self.groups, self.eps, True)
         if self.conv_shortcut is not None:
             M = B * N
@@ -83,24 +84,20 @@ class ResnetBlock1D(nn.Module):
         else:
             res = x1
         out, _ = E.conv3_fwd(a2, st.w(self.conv2.weight), st.f(self.conv2.bias), B, N, cin=Cout, cout=Cout, residual=res)
-        return out, (x1, x2, a1, s1, h1, a2, s2, semb, B, N)
+        return out, (x1, x2, a1, s1, h1, a2, s2, B, N)
 
-    def bwd(self, st, saved, dout, dsemb):
-        """Returns (dx1, dx2); accumulates the time-embedding gradient into dsemb (f32 (B, 4*C0)) in place."""
-        x1, x2, a1, s1, h1, a2, s2, semb, B, N = saved
+    def bwd(self, st, saved, dout, dtproj):
+        """Returns (dx1, dx2); writes d(time-embedding projection) into this block's (B, Cout) slice `dtproj` (zeroed)."""
+        x1, x2, a1, s1, h1, a2, s2, B, N = saved
         Cin, Cout, M = self.in_channels, self.out_channels, B * N
         pt = ops.pt_dtype(x1)
         da2 = E.conv3_bwd(dout, a2, st.w(self.conv2.weight), st.g(self.conv2.weight), st.g(self.conv2.bias), B, N, N,
                           cin=Cout, cout=Cout)
         dh1, _ = E.groupnorm_bwd(da2, h1, None, s2, st.f(self.norm2.weight), st.f(self.norm2.bias),
                                  st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True)
-        # time-embedding projection: d tproj[b][c] = sum_n dh1[(b,n)][c]
-        dtproj = torch.zeros(B, Cout, dtype=torch.float32, device=x1.device)
-        ops.colsum(dh1, dtproj, M, Cout, seg_rows=N)
-        E.linear_bwd(dtproj, semb, st.f(self.time_emb_proj.weight), st.g(self.time_emb_proj.weight),
-                     st.g(self.time_emb_proj.bias), dx_accum=dsemb)
+        # time-embedding projection: d tproj[b][c] = sum_n dh1[(b,n)][c]  (its GEMMs are batched over all blocks by the UNet)
+        ops.colsum(dh1, dtproj, M, Cout, seg_rows=N, ld_out=dtproj.stride(0))
         da1 = E.conv3_bwd(dh1, a1, st.w(self.conv1.weight), st.g(self.conv1.weight), None, B, N, N, cin=Cin, cout=Cout)
-        ops.colsum(dtproj, st.g(self.conv1.bias), B, Cout)          # conv1 bias grad = sum_b dtproj
         if self.conv_shortcut is not None:
             w, gw = st.w(self.conv_shortcut.weight), st.g(self.conv_shortcut.weight).view(Cout, Cin)
             A = ops.concat(x1, x2, trans=True) if x2 is not None else ops.plain(x1, trans=True)

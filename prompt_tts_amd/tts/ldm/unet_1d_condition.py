@@ -87,6 +87,14 @@ class Unet1DConditionModel(nn.Module):
                 t, num_layers=rlpb[i] + 1, in_channels=ic, out_channels=oc, prev_output_channel=prev,
                 temb_channels=ted, add_upsample=not last, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
                 cross_attention_dim=cross_attention_dim, attn_num_head_channels=attention_head_dim))
+        # forward-order list of every ResnetBlock1D and its column offset in the batched time-embedding projection;
+        # this is also the order in which ParamStore packs the time_emb_proj tensors (module registration order)
+        self._resnets = [m for m in self.modules() if m.__class__.__name__ == "ResnetBlock1D"]
+        off = 0
+        for r in self._resnets:
+            r._tp_off = off
+            off += r.out_channels
+        self._tp_total = off
         self.conv_norm_out = nn.GroupNorm(norm_num_groups, boc[0], eps=norm_eps)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv1d(boc[0], out_channels, 3, padding=1)
@@ -110,6 +118,9 @@ class Unet1DConditionModel(nn.Module):
         s1 = torch.empty_like(e1); ops.silu_fwd(e1, s1)
         emb = E.linear_fwd(s1, st.f(te.linear_2.weight), st.f(te.linear_2.bias))
         semb = torch.empty_like(emb); ops.silu_fwd(emb, semb)
+        Wt, _, bt, _ = st.late_views()
+        tproj_all = E.linear_fwd(semb, Wt, bt)                       # (B, sum Cout) f32: one GEMM for every resnet
+        tp = lambda r: tproj_all[:, r._tp_off:r._tp_off + r.out_channels]
         tape["time"] = (t_emb, e1, s1, emb, semb)
 
         h, _ = E.conv3_fwd(xt, st.w(self.conv_in.weight), st.f(self.conv_in.bias), B, T, cin=self.cpad, cout=C0)
@@ -120,7 +131,7 @@ class Unet1DConditionModel(nn.Module):
         for blk in self.down_blocks:
             rec = []
             for j, r in enumerate(blk.resnets):
-                h, sv_r = r.fwd(st, h, None, semb, B, N)
+                h, sv_r = r.fwd(st, h, None, tp(r), B, N)
                 sv_a = None
                 if blk.attentions is not None:
                     h, sv_a = blk.attentions[j].fwd(st, h, ctx, B, N, S)
@@ -135,9 +146,9 @@ class Unet1DConditionModel(nn.Module):
         tape["down"] = down
         if self.mid_block is not None:
             mb = self.mid_block
-            h, m0 = mb.resnets[0].fwd(st, h, None, semb, B, N)
+            h, m0 = mb.resnets[0].fwd(st, h, None, tp(mb.resnets[0]), B, N)
             h, m1 = mb.attentions[0].fwd(st, h, ctx, B, N, S)
-            h, m2 = mb.resnets[1].fwd(st, h, None, semb, B, N)
+            h, m2 = mb.resnets[1].fwd(st, h, None, tp(mb.resnets[1]), B, N)
             tape["mid"] = (m0, m1, m2)
         up = []
         for blk in self.up_blocks:
@@ -146,7 +157,7 @@ class Unet1DConditionModel(nn.Module):
                 skip, n_skip = skips.pop()
                 if n_skip != N:
                     raise RuntimeError("skip / hidden length mismatch")
-                h, sv_r = r.fwd(st, h, skip, semb, B, N)
+                h, sv_r = r.fwd(st, h, skip, tp(r), B, N)
                 sv_a = None
                 if blk.attentions is not None:
                     h, sv_a = blk.attentions[j].fwd(st, h, ctx, B, N, S)
@@ -174,7 +185,8 @@ class Unet1DConditionModel(nn.Module):
         B, T, S = tape["dims"]
         C0 = cfg["block_out_channels"][0]
         t_emb, e1, s1, emb, semb = tape["time"]
-        dsemb = torch.zeros_like(semb)
+        dtp_all = torch.zeros(B, self._tp_total, dtype=torch.float32, device=semb.device)
+        dtp = lambda r: dtp_all[:, r._tp_off:r._tp_off + r.out_channels]
         notify = on_ready or (lambda m: None)
 
         h, a, s = tape["out"]
@@ -194,15 +206,15 @@ class Unet1DConditionModel(nn.Module):
                 sv_r, sv_a = rec[j]
                 if sv_a is not None:
                     dh, dctx = blk.attentions[j].bwd(st, sv_a, dh, dctx)
-                dh, dskip = blk.resnets[j].bwd(st, sv_r, dh, dsemb)
+                dh, dskip = blk.resnets[j].bwd(st, sv_r, dh, dtp(blk.resnets[j]))
                 dskips.append(dskip)
             notify(blk)
         if self.mid_block is not None:
             mb = self.mid_block
             m0, m1, m2 = tape["mid"]
-            dh, _ = mb.resnets[1].bwd(st, m2, dh, dsemb)
+            dh, _ = mb.resnets[1].bwd(st, m2, dh, dtp(mb.resnets[1]))
             dh, dctx = mb.attentions[0].bwd(st, m1, dh, dctx)
-            dh, _ = mb.resnets[0].bwd(st, m0, dh, dsemb)
+            dh, _ = mb.resnets[0].bwd(st, m0, dh, dtp(mb.resnets[0]))
             notify(mb)
         # down path: every block output was also a skip; dskips[i] is the up-path gradient of skips[i]
         for blk, (rec, sv_d) in zip(reversed(self.down_blocks), reversed(tape["down"])):
@@ -216,7 +228,7 @@ class Unet1DConditionModel(nn.Module):
                 ops.add(dh, ds, dh)
                 if sv_a is not None:
                     dh, dctx = blk.attentions[j].bwd(st, sv_a, dh, dctx)
-                dh, _ = blk.resnets[j].bwd(st, sv_r, dh, dsemb)
+                dh, _ = blk.resnets[j].bwd(st, sv_r, dh, dtp(blk.resnets[j]))
             notify(blk)
         ds = dskips.pop()
         ops.add(dh, ds, dh)
@@ -224,6 +236,12 @@ class Unet1DConditionModel(nn.Module):
         E.conv3_bwd(dh, xt, st.w(self.conv_in.weight), st.g(self.conv_in.weight), st.g(self.conv_in.bias), B, T, T,
                     cin=self.cpad, cout=C0, cin_store=cfg["in_channels"], need_dx=False)
         notify(self.conv_in)
+        # batched time-embedding projection backward: one dgrad + one wgrad + one column sum for all resnets; each
+        # conv1 bias gradient equals its slice of the projection-bias gradient (both are sum_b dtproj[b][c])
+        Wt, gWt, _, gbt = st.late_views()
+        dsemb = E.linear_bwd(dtp_all, semb, Wt, gWt, gbt)
+        for r in self._resnets:
+            ops.colsum(dtp(r), st.g(r.conv1.bias), B, r.out_channels)
         # time-embedding MLP backward (f32)
         te = self.time_embedding
         demb = torch.empty_like(emb); ops.silu_bwd(dsemb, emb, demb)

@@ -77,7 +77,7 @@ def test_cabi_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (pt_\w+)", out))
     assert exported >= declared
-    assert _lib.lib.pt_abi_version() >= 3
+    assert _lib.lib.pt_abi_version() >= 4
     assert b"aligned" in _lib.lib.pt_status_string(-4)
     # argument validation returns before any HIP call: safe without a GPU
     assert _lib.lib.pt_gemm(None, 1, None) == -5

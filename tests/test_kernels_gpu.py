@@ -303,6 +303,9 @@ def test_elementwise(dev, dtype):
     assert relerr(ps, af.view(32, 2, 128).sum(1)) < TOL[dtype]
     cs = torch.zeros(128, device=dev); ops.colsum(a, cs)
     assert relerr(cs, af.sum(0)) < TOL[dtype]
+    seg = torch.zeros(4, 200, device=dev)                 # segmented sums into a column slice of a wider matrix
+    ops.colsum(a, seg[:, 40:], 64, 128, seg_rows=16, ld_out=200)
+    assert relerr(seg[:, 40:168], af.view(4, 16, 128).sum(1)) < TOL[dtype] and float(seg[:, :40].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
