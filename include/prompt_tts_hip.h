@@ -83,8 +83,8 @@ typedef struct pt_gemm_desc {
   int64_t row_bias_ld;           /* stride between row_bias rows (0: N) -- lets it be a column slice of a wider matrix */
   const void* residual; int64_t ldr;   /* same dtype as activations, or NULL                      */
   const void* residual2; int64_t ldr2; /* second addend (may alias C: in-place accumulation)      */
-  int32_t conv_wgrad_cin;        /* > 0: C index (m, n=tap*cin+ci) -> m*3*cin + ci*3 + tap (reference Conv1d weight layout) */
-  int32_t conv_wgrad_cin_store;  /* real Cin of the stored weight when cin is padded (conv_in)    */
+  int32_t conv_wgrad_cin;        /* > 0 (padded-Cin conv wgrad): C index (m, n=tap*cin+ci) -> (m*3 + tap)*cin_store + ci, ci >= cin_store dropped */
+  int32_t conv_wgrad_cin_store;  /* real Cin of the stored [Cout][3][Cin] gradient                 */
   float alpha;                   /* scales the accumulator before the epilogue adds               */
   int32_t act;                   /* 0 none, 1 ELU(alpha=1) applied to what is stored in C         */
   int32_t act2;                  /* same for the optional second output                            */
@@ -194,7 +194,9 @@ int pt_sumsq(const float* g, float* out, int64_t n, pt_stream stream);
 
 /* One fused AdamW step over a flat f32 master buffer (torch.optim.AdamW semantics, train.py:41-47,116-120):
  * clip = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) read on device; p -= lr*wd*p; m,v update; p -= step.
- * Also refreshes the activation-dtype weight shadow.  seg = table of n_seg tensors (pt_param_seg). */
+ * Also refreshes the activation-dtype weight shadow.  seg = table of n_seg tensors (pt_param_seg).
+ * Gradients of layout-1 (Conv1d k=3) tensors are stored [Cout][3][Cin] (what the wgrad GEMM writes with contiguous
+ * atomics); p, m, v keep the reference (Cout, Cin, 3) order. */
 typedef struct pt_param_seg {
   int64_t offset;        /* element offset in the flat master / grad / m / v buffers            */
   int64_t numel;

@@ -32,6 +32,7 @@ struct VOp {
   int cin_shift, nout_shift;   // log2 when a power of two, else -1
   int seg_kt;                  // k-tiles over which a chunk's address advances by `step` bytes per k-tile (1: recompute always)
   int64_t step;                // bytes per k-tile inside a segment
+  int edge_slow;               // also recompute at positions 1 and seg_kt-1 of a segment (conv rows at batch-item edges)
   int64_t rows, cols;   // logical extent of the virtual matrix
 };
 
@@ -142,17 +143,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
   const int last_kt = nkt_total - 1;
   const bool ktail = (p.K % BK) != 0;
-  int a_left = p.A.seg_kt - kt_begin % p.A.seg_kt, b_left = p.B.seg_kt - kt_begin % p.B.seg_kt;
+  int a_pos = kt_begin % p.A.seg_kt, b_pos = kt_begin % p.B.seg_kt;     // position of the k-tile inside its segment
   auto stage = [&](int kt, int stg, bool fresh) {
     const int64_t k0 = (int64_t)kt * BK;
     char* sa = smem + stg * 2 * STAGE_BYTES;
     char* sb = sa + STAGE_BYTES;
     const bool tail = ktail && kt == last_kt;
-    bool slow_a = fresh || tail, slow_b = fresh || tail;
     if (!fresh) {
-      if (--a_left == 0) { slow_a = true; a_left = p.A.seg_kt; }
-      if (--b_left == 0) { slow_b = true; b_left = p.B.seg_kt; }
+      if (++a_pos == p.A.seg_kt) a_pos = 0;
+      if (++b_pos == p.B.seg_kt) b_pos = 0;
     }
+    const bool slow_a = fresh || tail || a_pos == 0 || (p.A.edge_slow && (a_pos == 1 || a_pos == p.A.seg_kt - 1));
+    const bool slow_b = fresh || tail || b_pos == 0 || (p.B.edge_slow && (b_pos == 1 || b_pos == p.B.seg_kt - 1));
     if (slow_a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           const int64_t m = m0 + wm * 64 + 16 * i + 4 * g + r;
           if (m >= p.M) continue;
           int64_t idx;
-          if (p.conv_wgrad_cin > 0) {
+          if (p.conv_wgrad_cin > 0) {           // padded-Cin conv (conv_in): drop the pad channels, keep [Cout][3][Cin]
             const int tap = (int)n / p.conv_wgrad_cin, ci = (int)n - tap * p.conv_wgrad_cin;
             if (ci >= p.conv_wgrad_cin_store) continue;
-            idx = (m * p.conv_wgrad_cin_store + ci) * 3 + tap;
+            idx = (m * 3 + tap) * p.conv_wgrad_cin_store + ci;
           } else {
             idx = m * p.ldc + n;
           }
@@ -359,7 +361,7 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
   v.rows = rows; v.cols = cols;
   // segment / step of the incremental addressing (see stage()): bk elements per k-tile
   const int bk = 128 / es;
-  v.seg_kt = 1; v.step = 0;
+  v.seg_kt = 1; v.step = 0; v.edge_slow = 0;
   if (!o.trans) {                               // reduction along columns
     v.step = (int64_t)bk * es;
     if (o.kind == PT_V_PLAIN) v.seg_kt = 1 << 30;
@@ -369,6 +371,13 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
     if (o.kind == PT_V_PLAIN) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
     else if (o.kind == PT_V_CONCAT && o.ld == o.ld2) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
     else if (o.kind == PT_V_WFLIP && v.cin % bk == 0) { v.seg_kt = v.cin / bk; v.step = (int64_t)bk * 3 * o.ld * es; }
+    else if (o.kind == PT_V_CONV && v.n_out % bk == 0 && v.n_out / bk >= 4 && o.rowmap <= PT_MAP_UP2) {
+      // wgrad operand: rows walk one batch item (n_out rows = seg_kt k-tiles) linearly; only the first / last rows of
+      // the item can be padding, so the first two and the last k-tile of each item are recomputed
+      v.seg_kt = v.n_out / bk; v.edge_slow = 1;
+      const int64_t rows_per_kt = o.rowmap == PT_MAP_S1 ? bk : (o.rowmap == PT_MAP_S2 ? 2 * bk : bk / 2);
+      v.step = rows_per_kt * o.ld * es;
+    }
   }
   return v;
 }

@@ -55,7 +55,14 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
       if (local >= sg.numel) continue;                 // alignment padding between tensors
       float pv = p[i];
       if (UPDATE && !sg.frozen) {
-        const float gv = g[i] * clip;
+        int64_t gi = i;
+        if (sg.layout == 1) {                          // conv k=3 gradients live as [Cout][3][Cin]
+          const int64_t per_co = (int64_t)sg.cin * 3;
+          const int64_t co = local / per_co; const int rem = (int)(local - co * per_co);
+          const int ci = rem / 3, tap = rem - ci * 3;
+          gi = sg.offset + (co * 3 + tap) * sg.cin + ci;
+        }
+        const float gv = g[gi] * clip;
         pv *= 1.f - lr * wd;
         const float mv = b1 * m[i] + (1.f - b1) * gv;
         const float vv = b2 * v[i] + (1.f - b2) * gv * gv;

@@ -96,8 +96,19 @@ class ParamStore:
         return self.shadow[i["soff"]:i["soff"] + i["sn"]].view(i["sshape"])
 
     def g(self, p):
+        """Gradient storage as the kernels write it: Conv1d k=3 weights as [Cout][3*Cin], everything else as p.shape."""
         i = self.info[id(p)]
-        return self.flat_g[i["off"]:i["off"] + i["n"]].view(p.shape)
+        flat = self.flat_g[i["off"]:i["off"] + i["n"]]
+        if p.dim() == 3 and p.shape[2] == 3:
+            return flat.view(p.shape[0], 3 * p.shape[1])
+        return flat.view(p.shape)
+
+    def grad_view(self, p):
+        """The gradient in the parameter's own (reference) shape -- a strided view for Conv1d k=3 weights."""
+        g = self.g(p)
+        if p.dim() == 3 and p.shape[2] == 3:
+            return g.view(p.shape[0], 3, p.shape[1]).permute(0, 2, 1)
+        return g
 
     def f(self, p):
         return p.data
@@ -135,7 +146,7 @@ class ParamStore:
     def attach_grads(self):
         for p in self.params:
             if not self.info[id(p)]["frozen"]:
-                p.grad = self.g(p)
+                p.grad = self.grad_view(p)
 
     def refresh_shadow(self):
         ops.pack_shadow(self.flat_p, self.shadow, self.seg_dev, self.n_seg)
@@ -229,14 +240,15 @@ def conv3_fwd(x, w3, bias, B, n_in, rowmap=L.PT_MAP_S1, cin=None, cout=None, row
 
 def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None, cout=None, cin_store=None,
               need_dx=True, dx_residual=None):
-    """dy: (B*n_out, cout[pad]); x: (B*n_in, cin).  gw: f32 (Cout, Cin_store, 3) view of the flat grad buffer."""
+    """dy: (B*n_out, cout[pad]); x: (B*n_in, cin).  gw: f32 [Cout][3*Cin_store] view of the flat grad buffer."""
     cin = x.shape[1] if cin is None else cin
     cout = dy.shape[1] if cout is None else cout           # channels the conv reads from dy (may be padded)
     pt = ops.pt_dtype(x)
     Mred = B * n_out
+    padded = cin_store is not None and cin_store != cin
     ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
-             gw, pt, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
-             conv_wgrad_cin=cin, conv_wgrad_cin_store=cin_store or cin)
+             gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
+             conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0)
     if gbias is not None:
         ops.colsum(dy, gbias, Mred, gbias.numel())
     if not need_dx:

@@ -142,12 +142,21 @@ def test_conv_dgrad_wgrad(dev, dtype, mode):
     rowmap = L.PT_MAP_S1 if stride == 1 else L.PT_MAP_S2_DGRAD
     ops.gemm(B * Nin, Cin, 3 * Cout, ops.conv(dyt, Cout, Nin, Nout, rowmap), ops.wflip(ws, Cout, Cin), dx, ops._DT[dtype])
     assert relerr(_untok(dx, B), xf.grad) < TOL[dtype]
-    # wgrad into the reference (Cout, Cin, 3) layout
-    dw = torch.zeros(Cout, Cin, 3, dtype=torch.float32, device=dev)
+    # wgrad in the kernel layout [Cout][3][Cin]
+    dw = torch.zeros(Cout, 3 * Cin, dtype=torch.float32, device=dev)
     rm = L.PT_MAP_S1 if stride == 1 else L.PT_MAP_S2
     ops.gemm(Cout, 3 * Cin, B * Nout, ops.plain(dyt, trans=True), ops.conv(xt, Cin, Nout, Nin, rm, trans=True), dw,
-             ops._DT[dtype], out_kind=L.PT_OUT_F32_ATOMIC, split_k=2, conv_wgrad_cin=Cin)
-    assert relerr(dw, wf.grad) < TOL[dtype]
+             ops._DT[dtype], out_kind=L.PT_OUT_F32_ATOMIC, split_k=2)
+    assert relerr(dw.view(Cout, 3, Cin).permute(0, 2, 1), wf.grad) < TOL[dtype]
+    # padded-Cin variant (conv_in): x carries 8 channels of which 5 are real; the stored gradient is [Cout][3][5]
+    x8 = torch.zeros(B, 8, Nin).to(dtype); x8[:, :5] = x[:, :5]
+    w5 = wf.detach()[:, :5].clone().requires_grad_(True)
+    F.conv1d(x8[:, :5].float(), w5, None, stride=stride, padding=1).backward(dy.float())
+    dw5 = torch.zeros(Cout, 15, dtype=torch.float32, device=dev)
+    x8t = _tok(x8).to(dev)
+    ops.gemm(Cout, 24, B * Nout, ops.plain(dyt, trans=True), ops.conv(x8t, 8, Nout, Nin, rm, trans=True), dw5,
+             ops._DT[dtype], out_kind=L.PT_OUT_F32_ATOMIC, conv_wgrad_cin=8, conv_wgrad_cin_store=5)
+    assert relerr(dw5.view(Cout, 3, 5).permute(0, 2, 1), w5.grad) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
