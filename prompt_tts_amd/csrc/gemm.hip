@@ -137,45 +137,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
   // data chunk (q%TCH)^swz(k): the swizzle lives in the SOURCE address.
   const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
-  // Per-chunk source pointers live in registers and advance by a per-operand byte step; they are recomputed from
-  // scratch (vaddr) only at segment boundaries, tracked with down-counters (no division in the loop).
+  // Per-chunk source pointers live in registers and advance by a per-chunk byte step (0 for chunks parked on the zero
+  // page): 2 VALU per chunk per k-tile.  They are recomputed from scratch (vaddr) only when a countdown reaches zero:
+  // first k-tile, new conv tap / concat half, batch-item edges of a conv-wgrad operand, the K-tail tile.
+  // (PMC: the loop was instruction-issue bound -- MFMA pipes 17 % busy, ~225 instructions per k-tile per wave.)
   const char* pa[4]; const char* pb[4];
+  uint32_t sta[4], stb[4];
   const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
   const int last_kt = nkt_total - 1;
   const bool ktail = (p.K % BK) != 0;
-  int a_pos = kt_begin % p.A.seg_kt, b_pos = kt_begin % p.B.seg_kt;     // position of the k-tile inside its segment
-  auto stage = [&](int kt, int stg, bool fresh) {
-    const int64_t k0 = (int64_t)kt * BK;
+  int until_slow = 0;                           // k-tiles that may still take the fast path
+  auto fast_tiles_after = [&](int kt) {         // evaluated only on the slow path
+    auto dist = [&](const VOp& o) {
+      const int pos = kt % o.seg_kt;
+      int d = o.seg_kt - pos;
+      if (o.edge_slow) { if (pos == 0) d = 1; else if (pos < o.seg_kt - 1) d = min(d, o.seg_kt - 1 - pos); }
+      return d;
+    };
+    int d = min(dist(p.A), dist(p.B));
+    if (ktail && kt < last_kt) d = min(d, last_kt - kt);
+    return d - 1;
+  };
+  auto stage = [&](int kt, int stg) {
     char* sa = smem + stg * 2 * STAGE_BYTES;
     char* sb = sa + STAGE_BYTES;
-    const bool tail = ktail && kt == last_kt;
-    if (!fresh) {
-      if (++a_pos == p.A.seg_kt) a_pos = 0;
-      if (++b_pos == p.B.seg_kt) b_pos = 0;
-    }
-    const bool slow_a = fresh || tail || a_pos == 0 || (p.A.edge_slow && (a_pos == 1 || a_pos == p.A.seg_kt - 1));
-    const bool slow_b = fresh || tail || b_pos == 0 || (p.B.edge_slow && (b_pos == 1 || b_pos == p.B.seg_kt - 1));
-    if (slow_a) {
+    if (until_slow == 0) {
+      const int64_t k0 = (int64_t)kt * BK;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = tid + 256 * i;
         if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
         else     { const int k = q / TCH; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[i] = (pa[i] == zero_page) ? zero_page : pa[i] + p.A.step;
-    }
-    if (slow_b) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = tid + 256 * i;
         if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
         else     { const int k = q / TCH; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+        sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
+        stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
       }
+      until_slow = fast_tiles_after(kt);
     } else {
+      --until_slow;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pb[i] = (pb[i] == zero_page) ? zero_page : pb[i] + p.B.step;
+      for (int i = 0; i < 4; ++i) { pa[i] += sta[i]; pb[i] += stb[i]; }
     }
     if (PT_GEMM_ABLATE == 2) return;
 #pragma unroll
@@ -186,13 +188,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
   };
 
-  stage(kt_begin, 0, true);
+  stage(kt_begin, 0);
   __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = kt + 1 < kt_end;
-    if (more) stage(kt + 1, cur ^ 1, false);
+    if (more) stage(kt + 1, cur ^ 1);
     const char* sa = smem + cur * 2 * STAGE_BYTES;
     const char* sb = sa + STAGE_BYTES;
 #pragma unroll
@@ -458,6 +460,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
   p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
+  if (p.A.step >= (1ll << 32) || p.B.step >= (1ll << 32)) { p.A.seg_kt = 1; p.B.seg_kt = 1; p.A.edge_slow = p.B.edge_slow = 0; }   // absurd strides: always recompute
   p.C = reinterpret_cast<char*>(d->C); p.ldc = d->ldc;
   p.out_kind = d->out_kind; p.split_k = d->split_k;
   p.bias = d->bias; p.row_bias = d->row_bias; p.row_bias_rows = d->row_bias_rows; p.row_bias_ld = d->row_bias_ld > 0 ? d->row_bias_ld : d->N;

@@ -47,6 +47,12 @@ def run(lib, M, N, K, iters=30):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--pmc":      # one shape on the product library, for rocprofv3 --pmc runs
+        lib = C.CDLL(L.LIB_PATH)
+        lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
+        name, M, N, K = SHAPES[int(sys.argv[2])]
+        print(name, run(lib, M, N, K, iters=10), "us")
+        sys.exit(0)
     variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]
     libs = {v: build(v) for v in variants}
     print("shape".ljust(18) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
