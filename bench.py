@@ -153,12 +153,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")        # "gloo": rehearsal of the N>1 path on a single GPU
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from prompt_tts_amd.tts.models import TTSSingleSpeaker
     from prompt_tts_amd import parallel, ops
