@@ -253,6 +253,16 @@ typedef struct pt_lstm2_desc {
 } pt_lstm2_desc;
 int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.
+ * ---------------------------------------------------------------------------------------------- */
+/* codes[i] = clamp(rint((x[i] + 1) / 2 * (bins-1)), 0, bins-1): inverse of the collate normalisation (dataloader.py:64,143). */
+int pt_codes_from_continuous(const float* x, int64_t* codes, int64_t n, int64_t bins, pt_stream stream);
+/* Per row of logits[R][V] (RVQ-codebook logits head output): k == 1 greedy argmax (lowest index on ties); k > 1: softmax
+ * over the k largest at `temperature`, inverse-CDF draw with the INJECTED uniform[row] in [0,1).  V <= 2048, k <= 64. */
+int pt_sample_topk(const void* logits, int64_t ld, const float* uniforms, int64_t* out, int64_t R, int64_t V, int64_t k,
+                   float temperature, int dtype, pt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

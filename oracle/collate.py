@@ -47,3 +47,18 @@ def collate(items, max_seq_length):
     if "text_norm" in items[0]:
         out["text_norm"] = [it["text_norm"] for it in items]
     return out
+
+
+def sample_topk(logits, k=1, uniforms=None, temperature=1.0):
+    """Build-defined oracle of greedy / top-k sampling (SURVEY 8a'): torch.topk order, softmax over the k, inverse-CDF
+    draw with injected uniforms (first j with cdf_j > u * total)."""
+    import torch
+    logits = torch.as_tensor(logits, dtype=torch.float32)
+    if k == 1:
+        return torch.argmax(logits, dim=-1)
+    v, i = torch.topk(logits, k, dim=-1)
+    e = torch.exp((v - v[:, :1]) / temperature)
+    cdf = torch.cumsum(e, dim=-1)
+    u = torch.as_tensor(uniforms, dtype=torch.float32)[:, None] * cdf[:, -1:]
+    pick = (cdf > u).float().argmax(dim=-1)
+    return i.gather(1, pick[:, None])[:, 0]

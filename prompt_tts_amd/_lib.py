@@ -95,6 +95,8 @@ SIGNATURES = {
     "pt_rvq_decode": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_rowconv": [C.POINTER(pt_rowconv_desc), _i32, _vp],
     "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],
+    "pt_codes_from_continuous": [_vp, _vp, _i64, _i64, _vp],
+    "pt_sample_topk": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
 }
 
 

@@ -230,6 +230,23 @@ def pack_shadow(p, shadow, seg_dev, n_seg):
           "pt_pack_shadow")
 
 
+def codes_from_continuous(x, bins=1024):
+    """(B, n_q, T) f32 in [-1, 1] -> int64 code indices (inverse of the collate normalisation)."""
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    check(lib.pt_codes_from_continuous(_p(x), _p(out), x.numel(), bins, _stream()), "pt_codes_from_continuous")
+    return out
+
+
+def sample_topk(logits, k=1, uniforms=None, temperature=1.0):
+    """logits (R, V) -> int64 (R,): greedy (k=1) or top-k sampling with injected uniforms."""
+    R, V = logits.shape
+    out = torch.empty(R, dtype=torch.int64, device=logits.device)
+    check(lib.pt_sample_topk(_p(logits), logits.stride(0), _p(uniforms), _p(out), R, V, k, temperature, pt_dtype(logits),
+                             _stream()), "pt_sample_topk")
+    return out
+
+
 # ---- per-symbol device timing (bench.py --kernel-timing): HIP events around every C-ABI call of one step ----------
 
 def profile_one_step(step_fn):
