@@ -16,6 +16,7 @@
 // no transposes, no im2col, no concat copies.
 //
 // Roofline: MFMA-bound for K >= 512 (2*128*128*K flops per 2*128*K*sizeof(T) operand bytes per tile).
+#include <stdlib.h>
 #include "mma.h"
 
 #ifndef PT_GEMM_ABLATE
@@ -96,19 +97,32 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
   return reinterpret_cast<const char*>(ptr);
 }
 
-constexpr int BM = 128, BN = 128;
-constexpr int STAGE_BYTES = 16384;   // one operand tile image
+constexpr int BN = 128;
+constexpr int B_BYTES = 16384;          // B operand tile image (128 rows/cols x 128 B)
 constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
+// Two tile configurations (tools/gemm_probe.py: the kernel is bound by L2 -> LDS operand traffic, ~15 TB/s with
+// 64 KB in flight per CU while the MFMA-only loop runs at ~1.2 PF):
+//   BM = 128: 4 waves, 2 LDS stages, 72 KiB  -> two workgroups per CU (small problems, few tiles)
+//   BM = 256: 8 waves, 3 LDS stages, 160 KiB -> one workgroup per CU, 25 % fewer operand bytes per flop and two
+//             k-tiles (96 KB) in flight behind a counted s_waitcnt vmcnt + raw s_barrier
+template <int BM_> struct TileCfg {
+  static constexpr int BM = BM_, NTHREADS = 2 * BM_, NWAVES = NTHREADS / 64, NSTAGE = BM_ == 256 ? 3 : 2;
+  static constexpr int A_BYTES = BM_ * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_CHUNKS = 4, B_CHUNKS = 1024 / NTHREADS;        // 16-byte chunks per thread per k-tile
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + NWAVES * SCRATCH_PER_WAVE;
+};
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM>
+__global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const GemmParams p) {
+  using Cfg = TileCfg<BM>;
+  constexpr int NTHREADS = Cfg::NTHREADS, NSTAGE = Cfg::NSTAGE, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
   constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
-  constexpr int TCH = 128 / EPC;                   // chunks per TileT row (128 columns)
-  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES + 4 * SCRATCH_PER_WAVE];
+  constexpr int TCHA = BM / EPC, TCHB = BN / EPC;  // chunks per TileT row of the A / B image
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;          // (BM/64) x 2 waves of 64 x 64
   const int g = lane >> 4, li = lane & 15;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
@@ -141,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // page): 2 VALU per chunk per k-tile.  They are recomputed from scratch (vaddr) only when a countdown reaches zero:
   // first k-tile, new conv tap / concat half, batch-item edges of a conv-wgrad operand, the K-tail tile.
   // (PMC: the loop was instruction-issue bound -- MFMA pipes 17 % busy, ~225 instructions per k-tile per wave.)
-  const char* pa[4]; const char* pb[4];
-  uint32_t sta[4], stb[4];
+  const char* pa[Cfg::A_CHUNKS]; const char* pb[Cfg::B_CHUNKS];
+  uint32_t sta[Cfg::A_CHUNKS], stb[Cfg::B_CHUNKS];
   const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
   const int last_kt = nkt_total - 1;
   const bool ktail = (p.K % BK) != 0;
@@ -159,44 +173,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     return d - 1;
   };
   auto stage = [&](int kt, int stg) {
-    char* sa = smem + stg * 2 * STAGE_BYTES;
-    char* sb = sa + STAGE_BYTES;
+    char* sa = smem + stg * STAGE_BYTES;
+    char* sb = sa + A_BYTES;
     if (until_slow == 0) {
       const int64_t k0 = (int64_t)kt * BK;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = tid + 256 * i;
+      for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
+        const int q = tid + NTHREADS * i;
         if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCH; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
-        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCH; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCH) ^ tilet_swz(k)) * EPC); }
+        else     { const int k = q / TCHA; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
         sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
+      }
+#pragma unroll
+      for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
+        const int q = tid + NTHREADS * i;
+        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHB; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
         stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
       }
       until_slow = fast_tiles_after(kt);
     } else {
       --until_slow;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { pa[i] += sta[i]; pb[i] += stb[i]; }
+      for (int i = 0; i < Cfg::A_CHUNKS; ++i) pa[i] += sta[i];
+#pragma unroll
+      for (int i = 0; i < Cfg::B_CHUNKS; ++i) pb[i] += stb[i];
     }
     if (PT_GEMM_ABLATE == 2) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int lds_off = (wbase + 256 * i) * 16;
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + lds_off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + lds_off), 16, 0, 0);
-    }
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i)
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + (wbase + NTHREADS * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i)
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + (wbase + NTHREADS * i) * 16), 16, 0, 0);
   };
 
-  stage(kt_begin, 0);
-  __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
-
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = kt + 1 < kt_end;
-    if (more) stage(kt + 1, cur ^ 1);
-    const char* sa = smem + cur * 2 * STAGE_BYTES;
-    const char* sb = sa + STAGE_BYTES;
+  auto compute = [&](int stg) {
+    const char* sa = smem + stg * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < (PT_GEMM_ABLATE == 1 ? 0 : BK / 32); ++ks) {
       Frag<T> fa[4], fb[4];
@@ -204,12 +218,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (!TA) frag_load_k(fa[i], sa, wm * 64 + 16 * i + li, kb);
-        else     frag_load_t<128>(fa[i], sa, wm * 64 + 16 * i, kb, kb + 4, lane);
+        else     frag_load_t<BM>(fa[i], sa, wm * 64 + 16 * i, kb, kb + 4, lane);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (!TB) frag_load_k(fb[j], sb, wn * 64 + 16 * j + li, kb);
-        else     frag_load_t<128>(fb[j], sb, wn * 64 + 16 * j, kb, kb + 4, lane);
+        else     frag_load_t<BN>(fb[j], sb, wn * 64 + 16 * j, kb, kb + 4, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -219,8 +233,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
           else        mma16(acc[i][j], fb[j], fa[i]);   // D[row = n][col = m]: 4 consecutive n per lane
         }
     }
+  };
+  if (NSTAGE == 2) {
+    stage(kt_begin, 0);
+    __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    constexpr int PER_TILE = Cfg::A_CHUNKS + Cfg::B_CHUNKS;     // LDS-DMA instructions a thread issues per k-tile
+    stage(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      // retire k-tile kt (the younger one stays in flight), then rendezvous: every wave's pieces of kt have landed
+      // AND every wave is done reading the buffer that stage(kt + 2) overwrites
+      if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+      compute(cur);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
     __syncthreads();
-    cur ^= 1;
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
@@ -253,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   // residuals (vector loads).  Phase 2: activation + conversion, then the wave's 16 x 64 (bf16) / 16 x 32 (f32)
   // sub-tile goes through a wave-private XOR-swizzled LDS scratch and leaves as whole row segments, 16 B per lane.
   const bool out32 = sizeof(T) == 4 || p.out_kind == PT_OUT_F32;
-  char* scratch = smem + 4 * STAGE_BYTES + wave * SCRATCH_PER_WAVE;
+  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE;
   const int n_outs = p.C2 ? 2 : 1;
   const int64_t mrow0 = (PT_GEMM_ABLATE == 3) ? ((int64_t)1 << 40) : m0 + wm * 64;
 #pragma unroll
@@ -402,12 +441,31 @@ int check_operand(const pt_operand& o, int esize) {
   return PT_OK;
 }
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
-int launch(const GemmParams& p, hipStream_t s) {
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM>
+int launch_bm(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
+  if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
-  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM>), grid, dim3(2 * BM), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
+}
+
+// Tile choice; PT_GEMM_TILE=128|256 overrides it for A/B probing (tools/gemm_probe.py).
+inline int pick_bm(const GemmParams& p) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("PT_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+  if (forced == 128 || forced == 256) return forced;
+  // Measured on the training step (bench.py, config B): 71.7 ms/step with BM = 128 everywhere vs 74.7 ms with BM = 256
+  // (both ~830 TF on an isolated K = 2048 GEMM: the 256 tile halves the staging time but its LDS traffic -- DMA writes
+  // plus fragment reads -- no longer hides under the MFMAs).  Default 128; 256 stays selectable for probing.
+  (void)p;
+  return 128;
+}
+
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
+int launch(const GemmParams& p, hipStream_t s) {
+  return pick_bm(p) == 256 ? launch_bm<T, TA, TB, ATOMIC, KA, KB, 256>(p, s) : launch_bm<T, TA, TB, ATOMIC, KA, KB, 128>(p, s);
 }
 
 inline int kind_class(int kind) { return kind == PT_V_CONV ? 1 : (kind == PT_V_WFLIP ? 2 : 0); }
@@ -470,8 +528,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.conv_wgrad_cin_store = d->conv_wgrad_cin_store > 0 ? d->conv_wgrad_cin_store : d->conv_wgrad_cin;
   p.alpha = d->alpha;
   p.act = d->act; p.act2 = d->act2; p.C2 = reinterpret_cast<char*>(d->C2); p.ldc2 = d->ldc2;
-  p.tiles_m = (int)((d->M + BM - 1) / BM); p.tiles_n = (int)((d->N + BN - 1) / BN);
-  if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
+  p.tiles_m = p.tiles_n = 0;   // set per tile configuration in launch_bm
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);
   return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);
