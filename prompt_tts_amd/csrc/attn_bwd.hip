@@ -103,25 +103,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
         for (int kt = 0; kt < 2; ++kt) { mma16(s[qt][kt], a, fk[kt][ks]); mma16(dp[qt][kt], d, fv[kt][ks]); }
       }
     }
+    // masking is needed only on ragged / causal tiles: keep the common path free of per-element predicates
+    const bool need_mask = p.causal || (qs + 32 > p.Nq) || (kblk + 128 > nk);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int qb = qs + 16 * qt + 4 * g;
       float ls[4], de[4];
+      if (!need_mask) {
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(LSE + qb), d4 = *reinterpret_cast<const f32x4_t*>(DELTA + qb);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = qb + r; const bool ok = q < p.Nq;
-        ls[r] = ok ? LSE[q] * PT_LOG2E : 0.f; de[r] = ok ? DELTA[q] : 0.f;
-      }
+        for (int r = 0; r < 4; ++r) { ls[r] = l4[r] * PT_LOG2E; de[r] = d4[r]; }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int key = k0 + 16 * kt + li;
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[qt][kt][r] * sl2 - ls[r]);
+            s[qt][kt][r] = pv;
+            dp[qt][kt][r] = pv * (dp[qt][kt][r] - de[r]);
+          }
+      } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qb + r;
-          const bool ok = (q < p.Nq) && (key < nk) && !(p.causal && key > q);
-          const float pv = ok ? exp2f(s[qt][kt][r] * sl2 - ls[r]) : 0.f;
-          s[qt][kt][r] = pv;
-          dp[qt][kt][r] = pv * (dp[qt][kt][r] - de[r]);
+          const int q = qb + r; const bool ok = q < p.Nq;
+          ls[r] = ok ? LSE[q] * PT_LOG2E : 0.f; de[r] = ok ? DELTA[q] : 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int key = k0 + 16 * kt + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qb + r;
+            const bool ok = (q < p.Nq) && (key < nk) && !(p.causal && key > q);
+            const float pv = ok ? __builtin_amdgcn_exp2f(s[qt][kt][r] * sl2 - ls[r]) : 0.f;
+            s[qt][kt][r] = pv;
+            dp[qt][kt][r] = pv * (dp[qt][kt][r] - de[r]);
+          }
         }
       }
     }
@@ -225,17 +241,29 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
       }
     }
     const int key0 = t * 64;
+    if (!(p.causal || key0 + 64 > nk)) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + 16 * kt + 4 * g + r, q = q0 + 16 * qt + li;
-          const bool ok = (key < nk) && !(p.causal && key > q);
-          const float pv = ok ? exp2f(s[kt][qt][r] * sl2 - ls[qt]) : 0.f;
-          dp[kt][qt][r] = pv * (dp[kt][qt][r] - de[qt]);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[kt][qt][r] * sl2 - ls[qt]);
+            dp[kt][qt][r] = pv * (dp[kt][qt][r] - de[qt]);
+          }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 16 * kt + 4 * g + r, q = q0 + 16 * qt + li;
+            const bool ok = (key < nk) && !(p.causal && key > q);
+            const float pv = ok ? __builtin_amdgcn_exp2f(s[kt][qt][r] * sl2 - ls[qt]) : 0.f;
+            dp[kt][qt][r] = pv * (dp[kt][qt][r] - de[qt]);
+          }
+    }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       Frag<T> fds[2];

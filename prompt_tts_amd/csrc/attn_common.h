@@ -46,6 +46,37 @@ __device__ __forceinline__ void frag_load_n(Frag<float>& f, const char* base, in
   f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
 
+// Loop-invariant per-lane LDS byte offsets of the fragment reads (bf16 path).  The swizzle depends only on row bits
+// 0..3, so tiles 16 or 32 rows apart differ by an immediate: hoisting these out of the K/V loop removes ~10 VALU of
+// address arithmetic per fragment read (the loops were VALU-bound: ~15 VALU per MFMA).
+template <typename T, int D> struct FragOffsets {
+  using Cfg = AttnCfg<T, D>;
+  int rowread[Cfg::KS];        // image row (lane&15), head-dim chunk of k-step ks
+  int trread[Cfg::DT];         // transposed read: image row 4*(lane>>4) + ((lane&15)>>2), columns 16*dt + 4*((lane&15)&3)
+  __device__ __forceinline__ void init(int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+#pragma unroll
+    for (int ks = 0; ks < Cfg::KS; ++ks) rowread[ks] = Cfg::Img::chunk_off(li, (ks * 32 + 8 * g) / Cfg::EPC);
+#pragma unroll
+    for (int dt = 0; dt < Cfg::DT; ++dt) trread[dt] = Cfg::Img::chunk_off(4 * g + q, 2 * dt + (pp >> 1)) + ((pp & 1) << 3);
+  }
+};
+// bf16 fragment reads from precomputed offsets: tile_rows = first image row of the 16-row tile (multiple of 16)
+template <int ROWB>
+__device__ __forceinline__ void frag_read_rows(Frag<bf16_t>& f, const char* img, int off, int tile_row0) {
+  f.v = *reinterpret_cast<const bf16x8_t*>(img + off + tile_row0 * ROWB);
+}
+// transposed: elements 0..3 from image rows kb0 + 4g + q.., 4..7 from kb0 + 16 + ...  (kb0 multiple of 32)
+template <int ROWB>
+__device__ __forceinline__ void frag_read_tr(Frag<bf16_t>& f, const char* img, int off, int kb0) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + kb0 * ROWB));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + (kb0 + 16) * ROWB));
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  f.v = __builtin_bit_cast(bf16x8_t, r);
+}
+
 // Stage ROWS x D elements (rows row0.., clipped to `limit` rows -> zero fill) HBM -> registers -> LDS image.
 template <typename T, int D, int ROWS> struct TileStage {
   using Cfg = AttnCfg<T, D>;

@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int ks = 0; ks < KS; ++ks) frag_load_global(fq[qt][ks], Q + (int64_t)row * p.ldq + ks * 32 + 8 * g);
   }
 
+  constexpr bool FAST = sizeof(T) == 2;          // bf16: hoisted LDS offsets; f32 (parity mode): generic addressing
+  FragOffsets<T, D> fo; fo.init(lane);
   f32x4_t o[DT][2];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { o[dt][0] = (f32x4_t){0, 0, 0, 0}; o[dt][1] = (f32x4_t){0, 0, 0, 0}; }
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         Frag<T> fk;
-        frag_load_n<COLS>(fk, kimg, 16 * kt + li, ks * 32 + 8 * g);
+        if constexpr (FAST) frag_read_rows<Cfg::ROWB>(fk, kimg, fo.rowread[ks], 16 * kt);
+        else frag_load_n<COLS>(fk, kimg, 16 * kt + li, ks * 32 + 8 * g);
         mma16(s[kt][0], fk, fq[0][ks]);
         mma16(s[kt][1], fk, fq[1][ks]);
       }
@@ -87,14 +90,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m[qt], mx);
-      const float alpha = exp2f((m[qt] - mn) * sl2);
+      const float alpha = __builtin_amdgcn_exp2f((m[qt] - mn) * sl2);
       m[qt] = mn;
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f((s[kt][qt][r] - mn) * sl2);
+          const float pv = __builtin_amdgcn_exp2f((s[kt][qt][r] - mn) * sl2);
           s[kt][qt][r] = pv; rs += pv;
         }
       l[qt] = l[qt] * alpha + rs;
@@ -110,7 +113,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         Frag<T> fv;
-        frag_load_t<COLS>(fv, vimg, 16 * dt, 32 * st + 4 * g, 32 * st + 16 + 4 * g, lane);
+        if constexpr (FAST) frag_read_tr<Cfg::ROWB>(fv, vimg, fo.trread[dt], 32 * st);
+        else frag_load_t<COLS>(fv, vimg, 16 * dt, 32 * st + 4 * g, 32 * st + 16 + 4 * g, lane);
         mma16(o[dt][0], fv, fp[0]);
         mma16(o[dt][1], fv, fp[1]);
       }
