@@ -241,10 +241,10 @@ def main():
         mf = {k: v for k, v in kern.items() if "tflops" in v and k.startswith("gemm<" + args.dtype)}
         if mf:
             name = max(mf, key=lambda k: mf[k]["ms_total"])
-            tpl = {"NT": "false, false", "NN": "false, true", "TT": "true, true"}[name.split(",")[1]]
+            tpl = {"NN": "false, false", "NT": "false, true", "TT": "true, true"}[name.split(",")[1]]   # <TA, TB> of the label
             out["roofline_kernel"] = {
                 "kernel": name, "symbol": f"gemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'}, {tpl}, "
-                                          f"{'true' if 'atomic' in name else 'false'}, {'1' if name.endswith('conv') and not name.split(',')[1] == 'TT' else '0'}, ...>",
+                                          f"{'true' if 'atomic' in name else 'false'}, ..., 128>",
                 "bound": "mfma", "calls_per_step": mf[name]["calls"], "avg_us": mf[name]["ms_avg"] * 1e3,
                 "algorithmic_gflop_per_launch": mf[name]["gflop_avg"], "achieved": mf[name]["tflops"], "peak": peak,
                 "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "share_of_step": mf[name]["ms_total"] / (step_s * 1e3)}
