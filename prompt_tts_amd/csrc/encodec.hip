@@ -158,71 +158,75 @@ struct LstmParams {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// launch s: blockIdx.y = layer, its time step t = s - layer; blockIdx.x = slice of 16 hidden units; blockIdx.z = 64 batch rows
+// launch s: blockIdx.y = layer, its time step t = s - layer; blockIdx.x = slice of 16 hidden units; blockIdx.z = 16 batch
+// rows.  The four waves of a workgroup are the four gates (i, f, g, o) of those 16 units; each wave owns ONE 16 x 16
+// accumulator tile.  The recurrence is latency-bound (T+1 dependent launches), so the k loop is unrolled by 8 with all
+// fragment loads (L2-resident weights and h rows) issued ahead of the MFMAs, and the batch is spread over many small
+// workgroups (H/16 * 2 * B/16 of them) instead of a few big ones.
 template <typename T>
 __global__ __launch_bounds__(256) void lstm2_step_kernel(const LstmParams p, int s) {
   const int layer = blockIdx.y, t = s - layer;
   if (t < 0 || t >= p.T) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-  const int H = p.H, j0 = blockIdx.x * 16, b0 = blockIdx.z * 64;
-  __shared__ float sg[4][64][17];
+  const int H = p.H, j0 = blockIdx.x * 16, b0 = blockIdx.z * 16;
+  __shared__ float sg[4][16][17];
 
-  f32x4_t acc[4];                     // [batch tile]; natural layout: col = gate column li, rows = batch 4g + r
   const T* h0 = reinterpret_cast<const T*>(p.h0_seq);
   const T* h1 = reinterpret_cast<const T*>(p.h1_seq);
   const int gcol = wave * H + j0 + li;      // row of the weight matrix = gate column (wave = gate i,f,g,o)
+  f32x4_t acc;                              // natural layout: col = gate column li, rows = batch 4g + r
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = b0 + 16 * rt + 4 * g + r;
-      float init = 0.f;
-      if (b < p.B) init = layer == 0 ? to_f32<T>(reinterpret_cast<const T*>(p.xg0)[((int64_t)b * p.T + t) * 4 * H + gcol]) : p.bias1[gcol];
-      acc[rt][r] = init;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    float init = 0.f;
+    if (b < p.B) init = layer == 0 ? to_f32<T>(reinterpret_cast<const T*>(p.xg0)[((int64_t)b * p.T + t) * 4 * H + gcol]) : p.bias1[gcol];
+    acc[r] = init;
   }
   const T* W = layer == 0 ? reinterpret_cast<const T*>(p.whh0) : reinterpret_cast<const T*>(p.wcat1);
   const int ldw = layer == 0 ? H : 2 * H;
-  const int ksteps = ldw / 32;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int k0 = 32 * ks + 8 * g;
-    // which sequence feeds this k range: layer 0: h0_{t-1}; layer 1: [h0_t | h1_{t-1}]
-    const T* src; int tt; int kk = k0;
+  const int brow = b0 + li;
+  const bool bok = brow < p.B;
+  // source of the A operand for a k range: layer 0: h0_{t-1}; layer 1: [h0_t | h1_{t-1}]
+  auto a_ptr = [&](int k0) -> const T* {
+    const T* src; int tt, kk = k0;
     if (layer == 0) { src = h0; tt = t - 1; }
     else if (k0 < H) { src = h0; tt = t; }
     else { src = h1; tt = t - 1; kk = k0 - H; }
-    Frag<T> fw;
-    frag_load_global(fw, W + (int64_t)gcol * ldw + k0);
+    return (tt >= 0 && bok) ? src + ((int64_t)brow * p.T + tt) * H + kk : nullptr;
+  };
+  constexpr int U = 8;
+  for (int ks0 = 0; ks0 < ldw / 32; ks0 += U) {      // H multiple of 256 -> ldw/32 multiple of 8
+    Frag<T> fw[U], fa[U];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int b = b0 + 16 * rt + li;
-      Frag<T> fa;
-      if (tt >= 0 && b < p.B) frag_load_global(fa, src + ((int64_t)b * p.T + tt) * H + kk);
-      else frag_zero(fa);
-      mma16(acc[rt], fa, fw);          // D[row = batch][col = gate column]
+    for (int u = 0; u < U; ++u) {
+      const int k0 = 32 * (ks0 + u) + 8 * g;
+      frag_load_global(fw[u], W + (int64_t)gcol * ldw + k0);
+      const T* ap = a_ptr(k0);
+      if (ap) frag_load_global(fa[u], ap); else frag_zero(fa[u]);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mma16(acc, fa[u], fw[u]);      // D[row = batch][col = gate column]
   }
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sg[wave][16 * rt + 4 * g + r][li] = acc[rt][r];
+  for (int r = 0; r < 4; ++r) sg[wave][4 * g + r][li] = acc[r];
   __syncthreads();
   float* c = layer == 0 ? p.c0 : p.c1;
   T* hseq = reinterpret_cast<T*>(layer == 0 ? p.h0_seq : p.h1_seq);
-  for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-    const int bl = e >> 4, j = e & 15, b = b0 + bl;
-    if (b >= p.B) continue;
-    const float ig = sigmoid_f(sg[0][bl][j]), fg = sigmoid_f(sg[1][bl][j]), gg = tanhf(sg[2][bl][j]), og = sigmoid_f(sg[3][bl][j]);
-    const int64_t ci = (int64_t)b * H + j0 + j;
-    const float cprev = t == 0 ? 0.f : c[ci];
-    const float cn = fg * cprev + ig * gg;
-    const float hn = og * tanhf(cn);
-    c[ci] = cn;
-    const int64_t oi = ((int64_t)b * p.T + t) * H + j0 + j;
-    hseq[oi] = from_f32<T>(hn);
-    if (layer == 1) {
-      const float v = hn + to_f32<T>(reinterpret_cast<const T*>(p.x)[oi]);
-      reinterpret_cast<T*>(p.out_elu)[oi] = from_f32<T>(v < 0.f ? (__expf(v) - 1.f) : v);
+  {
+    const int bl = threadIdx.x >> 4, j = threadIdx.x & 15, b = b0 + bl;     // 256 threads = 16 batch rows x 16 units
+    if (b < p.B) {
+      const float ig = sigmoid_f(sg[0][bl][j]), fg = sigmoid_f(sg[1][bl][j]), gg = tanhf(sg[2][bl][j]), og = sigmoid_f(sg[3][bl][j]);
+      const int64_t ci = (int64_t)b * H + j0 + j;
+      const float cprev = t == 0 ? 0.f : c[ci];
+      const float cn = fg * cprev + ig * gg;
+      const float hn = og * tanhf(cn);
+      c[ci] = cn;
+      const int64_t oi = ((int64_t)b * p.T + t) * H + j0 + j;
+      hseq[oi] = from_f32<T>(hn);
+      if (layer == 1) {
+        const float v = hn + to_f32<T>(reinterpret_cast<const T*>(p.x)[oi]);
+        reinterpret_cast<T*>(p.out_elu)[oi] = from_f32<T>(v < 0.f ? (__expf(v) - 1.f) : v);
+      }
     }
   }
 }
@@ -269,7 +273,7 @@ extern "C" int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream)
 extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
   if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
-  if (d->B <= 0 || d->T <= 0 || d->H <= 0 || d->H % 32 != 0 || d->B > 64 * 65535) return PT_ERR_SHAPE;
+  if (d->B <= 0 || d->T <= 0 || d->H <= 0 || d->H % 256 != 0 || d->B > 16 * 65535) return PT_ERR_SHAPE;
   if (!d->x || !d->xg0 || !d->whh0 || !d->wcat1 || !d->bias1 || !d->h0_seq || !d->h1_seq || !d->c0 || !d->c1 || !d->out_elu) return PT_ERR_ARG;
   const void* ptrs[] = {d->x, d->xg0, d->whh0, d->wcat1, d->h0_seq, d->h1_seq, d->out_elu};
   for (const void* q : ptrs) if (!pt_aligned16(q)) return PT_ERR_ALIGN;
@@ -278,7 +282,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   p.x = (const char*)d->x; p.xg0 = (const char*)d->xg0; p.whh0 = (const char*)d->whh0; p.wcat1 = (const char*)d->wcat1;
   p.bias1 = d->bias1; p.h0_seq = (char*)d->h0_seq; p.h1_seq = (char*)d->h1_seq; p.c0 = d->c0; p.c1 = d->c1; p.out_elu = (char*)d->out_elu;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(d->H / 16), 2, (unsigned)((d->B + 63) / 64));
+  dim3 grid((unsigned)(d->H / 16), 2, (unsigned)((d->B + 15) / 16));
   for (int step = 0; step <= (int)d->T; ++step) {
     if (dtype == PT_F32) hipLaunchKernelGGL((lstm2_step_kernel<float>), grid, dim3(256), 0, s, p, step);
     else hipLaunchKernelGGL((lstm2_step_kernel<bf16_t>), grid, dim3(256), 0, s, p, step);
