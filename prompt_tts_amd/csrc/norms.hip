@@ -415,7 +415,7 @@ int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, 
   constexpr int EPC = Vec16<T>::N;
   const int chunks = (int)((C / EPC + 63) / 64);
   const int64_t want = (M + 3) / 4;
-  dim3 grid((unsigned)(want < 2048 ? want : 2048));
+  dim3 grid((unsigned)(want < 1024 ? want : 1024));       // 8 rows per wave at M = 32768: amortises the dgamma/dbeta atomics
 #define LN_B(MC) hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, M, (int)C)
   if (chunks <= 1) LN_B(1); else if (chunks <= 2) LN_B(2); else if (chunks <= 4) LN_B(4); else return PT_ERR_SHAPE;
 #undef LN_B
