@@ -177,6 +177,41 @@ class ParamStore:
 # layer executors (x, dy are token-major 2-D tensors)
 # ---------------------------------------------------------------------------------------------------------
 
+# ---- weight-gradient GEMMs on a side stream --------------------------------------------------------------------------
+# dgrad and wgrad of a layer both depend only on dy: the wgrad is issued on a second HIP stream so that it runs beside the
+# dgrad chain (the GEMMs are operand-latency bound, two resident kernels keep more loads in flight).  Its result is needed
+# only by the DP reducer / optimizer, which join the side stream first.
+WGRAD_SIDE_STREAM = True
+_side = {}
+
+
+def _side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = _side[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def on_side_stream(fn, *tensors):
+    """Run fn() (kernel launches reading `tensors`) on the wgrad side stream, ordered after the current stream."""
+    if not WGRAD_SIDE_STREAM:
+        fn()
+        return
+    dev = tensors[0].device
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)           # keep the caching allocator from recycling them under the side kernels
+
+
+def join_side_stream(device):
+    st = _side.get(device)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
 def _empty(rows, cols, like):
     return torch.empty(rows, cols, dtype=like.dtype, device=like.device)
 
@@ -204,12 +239,14 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
     M, N = dy.shape
     K = x.shape[1]
     pt = ops.pt_dtype(x)
-    ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
-             out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype))
-    if gbias is not None:
-        for c0 in range(0, N, 8192):                     # the column-sum kernel keeps its columns in LDS
-            c1 = min(N, c0 + 8192)
-            ops.colsum(dy[:, c0:c1], gbias[c0:c1], M, c1 - c0)
+    def wgrad():
+        ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
+                 out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype))
+        if gbias is not None:
+            for c0 in range(0, N, 8192):                 # the column-sum kernel keeps its columns in LDS
+                c1 = min(N, c0 + 8192)
+                ops.colsum(dy[:, c0:c1], gbias[c0:c1], M, c1 - c0)
+    on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else (dx_accum if dx_accum is not None else _empty(M, K, x))
@@ -246,11 +283,14 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
     pt = ops.pt_dtype(x)
     Mred = B * n_out
     padded = cin_store is not None and cin_store != cin
-    ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
-             gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
-             conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0)
-    if gbias is not None:
-        ops.colsum(dy, gbias, Mred, gbias.numel())
+
+    def wgrad():
+        ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
+                 gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
+                 conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0)
+        if gbias is not None:
+            ops.colsum(dy, gbias, Mred, gbias.numel())
+    on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
     if rowmap == L.PT_MAP_UP2:

@@ -195,11 +195,17 @@ class TTSSingleSpeaker(nn.Module):
         sv_text, utape, B, T, S = tape
         if next(p for p in st.params if not st.info[id(p)]["frozen"]).grad is None:
             st.zero_grad(); st.attach_grads()            # optimizer.zero_grad(set_to_none=True) dropped the views
-        hook = self.grad_ready_hook
+        user_hook = self.grad_ready_hook
+        hook = None
+        if user_hook is not None:
+            def hook(module):                     # weight gradients are produced on the side stream: join it first
+                E.join_side_stream(st.device)
+                user_hook(module)
         dctx = self.unet.bwd(st, utape, dpred, hook)
         self.text_encoder.bwd(st, sv_text, dctx)
         if hook is not None:
             hook(self.text_encoder)
+        E.join_side_stream(st.device)
 
     def _forward_impl(self, sample, t, ids, mask):
         st = self.store
