@@ -152,18 +152,19 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x1, 
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s[j][e] = 0.f; ss[j][e] = 0.f; }
-  if (rr < g.RP) {
-#pragma unroll 4
-    for (int r = r0 + rr; r < r1; r += g.RP) {
-      const int64_t row = (int64_t)b * g.N + r;
+  // one branch-free streaming loop per owned column chunk, unrolled so several 16-byte loads are in flight per thread
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = cw + j * g.CW;
-        if (j < g.J && c < g.CC) {
-          Vec16<T> v = load16(gn_src(x1, x2, g, row, c * EPC));
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+    if (rr < g.RP && j < g.J && c < g.CC) {
+      const int col = c * EPC;
+      const T* src = col < g.C1 ? x1 + col : x2 + (col - g.C1);
+      const int64_t ldx = col < g.C1 ? g.C1 : g.C2;
+#pragma unroll 8
+      for (int r = r0 + rr; r < r1; r += g.RP) {
+        Vec16<T> v = load16(src + ((int64_t)b * g.N + r) * ldx);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) { float f = v.get(e); s[j][e] += f; ss[j][e] += f * f; }
-        }
+        for (int e = 0; e < EPC; ++e) { float f = v.get(e); s[j][e] += f; ss[j][e] += f * f; }
       }
     }
   }
@@ -224,21 +225,24 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x1, 
       }
     }
   }
-#pragma unroll 4
-  for (int r = r0 + rr; r < r1; r += g.RP) {
-    const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = cw + j * g.CW;
-      if (j < g.J && c < g.CC) {
-        Vec16<T> v = load16(gn_src(x1, x2, g, row, c * EPC)), o;
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+    if (j < g.J && c < g.CC) {
+      const int col = c * EPC;
+      const T* src = col < g.C1 ? x1 + col : x2 + (col - g.C1);
+      const int64_t ldx = col < g.C1 ? g.C1 : g.C2;
+#pragma unroll 8
+      for (int r = r0 + rr; r < r1; r += g.RP) {
+        const int64_t row = (int64_t)b * g.N + r;
+        Vec16<T> v = load16(src + row * ldx), o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           float z = v.get(e) * sc[j][e] + sf[j][e];
           o.set(e, silu ? silu_f(z) : z);
         }
-        store16(y + row * g.C + c * EPC, o);
-        if (xcat) store16(xcat + row * g.C + c * EPC, v);
+        store16(y + row * g.C + col, o);
+        if (xcat) store16(xcat + row * g.C + col, v);
       }
     }
   }
@@ -270,23 +274,24 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ d
       }
     }
   }
-  if (rr < g.RP) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+    if (rr < g.RP && j < g.J && c < g.CC) {
+      const int col = c * EPC;
+      const T* src = col < g.C1 ? x1 + col : x2 + (col - g.C1);
+      const int64_t ldx = col < g.C1 ? g.C1 : g.C2;
 #pragma unroll 4
-    for (int r = r0 + rr; r < r1; r += g.RP) {
-      const int64_t row = (int64_t)b * g.N + r;
+      for (int r = r0 + rr; r < r1; r += g.RP) {
+        const int64_t row = (int64_t)b * g.N + r;
+        Vec16<T> vx = load16(src + row * ldx);
+        Vec16<T> vd = load16(dy + row * g.C + col);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = cw + j * g.CW;
-        if (j < g.J && c < g.CC) {
-          Vec16<T> vx = load16(gn_src(x1, x2, g, row, c * EPC));
-          Vec16<T> vd = load16(dy + row * g.C + c * EPC);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            const float xh = (vx.get(e) - mu[j][e]) * rs[j][e];
-            float dz = vd.get(e);
-            if (silu) dz *= silu_grad_f(xh * ga[j][e] + be[j][e]);
-            sg[j][e] += dz * xh; sb[j][e] += dz;
-          }
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (vx.get(e) - mu[j][e]) * rs[j][e];
+          float dz = vd.get(e);
+          if (silu) dz *= silu_grad_f(xh * ga[j][e] + be[j][e]);
+          sg[j][e] += dz * xh; sb[j][e] += dz;
         }
       }
     }
@@ -350,21 +355,24 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
       }
     }
   }
-#pragma unroll 4
-  for (int r = r0 + rr; r < r1; r += g.RP) {
-    const int64_t row = (int64_t)b * g.N + r;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = cw + j * g.CW;
-      if (j < g.J && c < g.CC) {
-        const int col0 = c * EPC;
-        Vec16<T> vx = load16(gn_src(x1, x2, g, row, col0));
+  for (int j = 0; j < 2; ++j) {
+    const int c = cw + j * g.CW;
+    if (j < g.J && c < g.CC) {
+      const int col0 = c * EPC;
+      const bool first = col0 < g.C1;
+      const T* src = first ? x1 + col0 : x2 + (col0 - g.C1);
+      T* dbase = first ? dx1 + col0 : dx2 + (col0 - g.C1);
+      const int64_t ldx = first ? g.C1 : g.C2;
+      const bool accum = acc_dx2 && !first;
+#pragma unroll 4
+      for (int r = r0 + rr; r < r1; r += g.RP) {
+        const int64_t row = (int64_t)b * g.N + r;
+        Vec16<T> vx = load16(src + row * ldx);
         Vec16<T> vd = load16(dy + row * g.C + col0);
-        Vec16<T> vr, o;
+        Vec16<T> vr, o, old;
         if (dres) vr = load16(dres + row * g.C + col0);
-        T* dst = col0 < g.C1 ? dx1 + row * g.C1 + col0 : dx2 + row * g.C2 + (col0 - g.C1);
-        const bool accum = acc_dx2 && col0 >= g.C1;
-        Vec16<T> old;
+        T* dst = dbase + row * ldx;
         if (accum) old = load16(dst);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
