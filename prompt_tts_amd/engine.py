@@ -216,10 +216,15 @@ def _empty(rows, cols, like):
     return torch.empty(rows, cols, dtype=like.dtype, device=like.device)
 
 
+SPLITK_TARGET_WGS = int(__import__("os").environ.get("PT_SPLITK_WGS", "256"))
+
+
 def _split_k(n_out, k_in, m_red, dtype):
+    # every split adds one 128x128 f32 tile of atomics per output tile (~1.3 TB/s chip-wide): as few splits as still fill
+    # the chip (the wgrad runs beside the dgrad chain on the side stream, so it need not fill all CUs by itself)
     tiles = math.ceil(n_out / 128) * math.ceil(k_in / 128)
     nkt = math.ceil(m_red / (64 if dtype == torch.bfloat16 else 32))
-    return max(1, min(512 // max(tiles, 1), nkt // 4, 64))
+    return max(1, min(SPLITK_TARGET_WGS // max(tiles, 1), nkt // 4, 64))
 
 
 def linear_fwd(x, w, bias=None, residual=None, residual2=None, out=None, out_f32=False):
