@@ -20,7 +20,7 @@
 #include "mma.h"
 
 #ifndef PT_GEMM_ABLATE
-#define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores
+#define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores, 4 all three (launch floor)
 #endif
 
 namespace {
@@ -97,32 +97,38 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
   return reinterpret_cast<const char*>(ptr);
 }
 
-constexpr int BN = 128;
-constexpr int B_BYTES = 16384;          // B operand tile image (128 rows/cols x 128 B)
 constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
-// Two tile configurations (tools/gemm_probe.py: the kernel is bound by L2 -> LDS operand traffic, ~15 TB/s with
-// 64 KB in flight per CU while the MFMA-only loop runs at ~1.2 PF):
-//   BM = 128: 4 waves, 2 LDS stages, 72 KiB  -> two workgroups per CU (small problems, few tiles)
-//   BM = 256: 8 waves, 3 LDS stages, 160 KiB -> one workgroup per CU, 25 % fewer operand bytes per flop and two
-//             k-tiles (96 KB) in flight behind a counted s_waitcnt vmcnt + raw s_barrier
-template <int BM_> struct TileCfg {
-  static constexpr int BM = BM_, NTHREADS = 2 * BM_, NWAVES = NTHREADS / 64, NSTAGE = BM_ == 256 ? 3 : 2;
-  static constexpr int A_BYTES = BM_ * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int A_CHUNKS = 4, B_CHUNKS = 1024 / NTHREADS;        // 16-byte chunks per thread per k-tile
+// Tile configurations (tools/gemm_probe.py: the kernel is bound by L2 -> LDS operand traffic, ~15 TB/s with 64 KB in
+// flight per CU, while the MFMA-only loop runs at ~1.2 PF; operand bytes per flop scale with 1/BM + 1/BN):
+//   128 x 128: 4 waves (2x2) of 64x64,  2 LDS stages,  72 KiB -> two workgroups per CU (small / few-tile problems)
+//   256 x 128: 8 waves (4x2) of 64x64,  3 LDS stages, 160 KiB -> counted s_waitcnt vmcnt + raw s_barrier, 2 tiles in flight
+//   256 x 256: 8 waves (2x4) of 128x64, 2 LDS stages, 144 KiB -> half the operand bytes per flop, 25 % fewer LDS
+//              fragment bytes per flop (128 accumulator registers per lane)
+template <int BM_, int BN_> struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_;
+  static constexpr int NWAVES = (BM_ == 128) ? 4 : 8, NTHREADS = 64 * NWAVES;
+  static constexpr int WAVES_N = BN_ / 64, WAVES_M = NWAVES / WAVES_N;
+  static constexpr int MI = BM_ / WAVES_M / 16, NJ = 4, WM = 16 * MI;      // per-wave tile WM x 64
+  static constexpr int NSTAGE = (BM_ == 256 && BN_ == 128) ? 3 : 2;
+  static constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_CHUNKS = BM_ * 8 / NTHREADS, B_CHUNKS = BN_ * 8 / NTHREADS;   // 16-byte chunks per thread per k-tile
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + NWAVES * SCRATCH_PER_WAVE;
+  static constexpr int MIN_WAVES_PER_SIMD = (BM_ == 128) ? 2 : 1;
 };
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM>
-__global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const GemmParams p) {
-  using Cfg = TileCfg<BM>;
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
+__global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_WAVES_PER_SIMD)) void gemm_kernel(const GemmParams p) {
+  using Cfg = TileCfg<BM, BN>;
   constexpr int NTHREADS = Cfg::NTHREADS, NSTAGE = Cfg::NSTAGE, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int MI = Cfg::MI, WM = Cfg::WM;
   constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
   constexpr int TCHA = BM / EPC, TCHB = BN / EPC;  // chunks per TileT row of the A / B image
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
 
+  if (PT_GEMM_ABLATE == 5) return;      // probe: pure dispatch cost
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;          // (BM/64) x 2 waves of 64 x 64
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;     // WAVES_M x WAVES_N waves of WM x 64
   const int g = lane >> 4, li = lane & 15;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
@@ -141,9 +147,9 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
   const int kt_end = min(nkt_total, kt_begin + per);
   if (kt_begin >= kt_end) return;
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
 #pragma unroll
       for (int i = 0; i < Cfg::B_CHUNKS; ++i) pb[i] += stb[i];
     }
-    if (PT_GEMM_ABLATE == 2) return;
+    if (PT_GEMM_ABLATE == 2 || PT_GEMM_ABLATE == 4) return;
 #pragma unroll
     for (int i = 0; i < Cfg::A_CHUNKS; ++i)
       __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + (wbase + NTHREADS * i) * 16), 16, 0, 0);
@@ -212,13 +218,13 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
     const char* sa = smem + stg * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < (PT_GEMM_ABLATE == 1 ? 0 : BK / 32); ++ks) {
-      Frag<T> fa[4], fb[4];
+    for (int ks = 0; ks < ((PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32); ++ks) {
+      Frag<T> fa[MI], fb[4];
       const int kb = ks * 32 + 8 * g;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (!TA) frag_load_k(fa[i], sa, wm * 64 + 16 * i + li, kb);
-        else     frag_load_t<BM>(fa[i], sa, wm * 64 + 16 * i, kb, kb + 4, lane);
+      for (int i = 0; i < MI; ++i) {
+        if (!TA) frag_load_k(fa[i], sa, wm * WM + 16 * i + li, kb);
+        else     frag_load_t<BM>(fa[i], sa, wm * WM + 16 * i, kb, kb + 4, lane);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
         else     frag_load_t<BN>(fb[j], sb, wn * 64 + 16 * j, kb, kb + 4, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (ATOMIC) mma16(acc[i][j], fa[i], fb[j]);   // D[row = m][col = n]
@@ -262,18 +268,19 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
     __syncthreads();
   }
 
+  if (PT_GEMM_ABLATE == 6) return;      // probe: everything but the epilogue code
   // ---- epilogue ------------------------------------------------------------------------------------
   if (ATOMIC) {
     float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t n = n0 + wn * 64 + 16 * j + li;
         if (n >= p.N) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t m = m0 + wm * 64 + 16 * i + 4 * g + r;
+          const int64_t m = m0 + wm * WM + 16 * i + 4 * g + r;
           if (m >= p.M) continue;
           int64_t idx;
           if (p.conv_wgrad_cin > 0) {           // padded-Cin conv (conv_in): drop the pad channels, keep [Cout][3][Cin]
@@ -293,10 +300,89 @@ __global__ __launch_bounds__(2 * BM, BM == 256 ? 1 : 2) void gemm_kernel(const G
   // sub-tile goes through a wave-private XOR-swizzled LDS scratch and leaves as whole row segments, 16 B per lane.
   const bool out32 = sizeof(T) == 4 || p.out_kind == PT_OUT_F32;
   char* scratch = smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE;
-  const int n_outs = p.C2 ? 2 : 1;
-  const int64_t mrow0 = (PT_GEMM_ABLATE == 3) ? ((int64_t)1 << 40) : m0 + wm * 64;
+  // Fast path (interior tile, bf16 output, 16-byte aligned rows): no per-element predicates at all.  The generic
+  // path below costs ~2500 executed instructions per wave -- as much as the MFMA work of a K = 512 tile.
+  if (sizeof(T) == 2 && !out32 && PT_GEMM_ABLATE != 3 && PT_GEMM_ABLATE != 4 && m0 + BM <= p.M && n0 + BN <= p.N &&
+      (p.ldc & 7) == 0 && (!p.C2 || (p.ldc2 & 7) == 0) && (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 &&
+      (reinterpret_cast<uintptr_t>(p.C2) & 15u) == 0) {
+    const int64_t mbase = m0 + wm * WM, nbase = n0 + wn * 64;
+    const int wr_off = li * 128 + ((g & 1) << 3);            // scratch write: row li, 8-byte half (g&1) of chunk 2j + (g>>1)
+    const int rd_row = lane >> 3, rd_c = lane & 7;           // scratch read: rows rd_row, rd_row + 8; chunk rd_c
+    const bool has_alpha = p.alpha != 1.0f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
+      const int64_t m = mbase + 16 * i + li;
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
+      if (has_alpha) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j][r] *= p.alpha;
+      }
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.bias + nbase + 16 * j + 4 * g);
+          v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
+        }
+      }
+      if (p.row_bias) {
+        const float* rb = p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld + nbase + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
+          v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
+        }
+      }
+      if (p.residual) {
+        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr + nbase + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
+          v[j][0] += __uint_as_float(t[0] << 16); v[j][1] += __uint_as_float(t[0] & 0xffff0000u);
+          v[j][2] += __uint_as_float(t[1] << 16); v[j][3] += __uint_as_float(t[1] & 0xffff0000u);
+        }
+      }
+      if (p.residual2) {
+        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual2) + m * p.ldr2 + nbase + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
+          v[j][0] += __uint_as_float(t[0] << 16); v[j][1] += __uint_as_float(t[0] & 0xffff0000u);
+          v[j][2] += __uint_as_float(t[1] << 16); v[j][3] += __uint_as_float(t[1] & 0xffff0000u);
+        }
+      }
+      for (int op = 0; op < (p.C2 ? 2 : 1); ++op) {
+        const int act = op == 0 ? p.act : p.act2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
+          u32x2_t o;
+          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+        }
+        bf16_t* Cb = reinterpret_cast<bf16_t*>(op == 0 ? p.C : p.C2) + (mbase + 16 * i) * (op == 0 ? p.ldc : p.ldc2) + nbase + 8 * rd_c;
+        const int64_t ld = op == 0 ? p.ldc : p.ldc2;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = 8 * it + rd_row;
+          *reinterpret_cast<u32x4_t*>(Cb + r * ld) = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+        }
+      }
+    }
+    return;
+  }
+  const int n_outs = p.C2 ? 2 : 1;
+  const int64_t mrow0 = (PT_GEMM_ABLATE == 3 || PT_GEMM_ABLATE == 4) ? ((int64_t)1 << 40) : m0 + wm * WM;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
     const int64_t m = mrow0 + 16 * i + li;
     const bool mok = m < p.M;
     const float* rbias = (p.row_bias && mok) ? p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld : nullptr;
@@ -441,31 +527,35 @@ int check_operand(const pt_operand& o, int esize) {
   return PT_OK;
 }
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM>
-int launch_bm(GemmParams p, hipStream_t s) {
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
+int launch_cfg(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
   if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
-  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM>), grid, dim3(2 * BM), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM, BN>), grid, dim3(TileCfg<BM, BN>::NTHREADS), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
 
-// Tile choice; PT_GEMM_TILE=128|256 overrides it for A/B probing (tools/gemm_probe.py).
-inline int pick_bm(const GemmParams& p) {
+// Tile choice; PT_GEMM_TILE=128|256|512 (= 128x128 | 256x128 | 256x256) overrides it for A/B probing (tools/gemm_probe.py).
+// Measured on the training step (config B): 256x256 wins for the forward linears (650-1040 TF isolated vs 550-910) but
+// its transposed-operand variants spill and the wgrads have too few tiles for it, so it is used for forward plain GEMMs
+// with at least one full round of 256x256 tiles; everything else runs 128x128 with two workgroups per CU.
+inline int pick_tile(const GemmParams& p, bool fwd_plain) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("PT_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-  if (forced == 128 || forced == 256) return forced;
-  // Measured on the training step (bench.py, config B): 71.7 ms/step with BM = 128 everywhere vs 74.7 ms with BM = 256
-  // (both ~830 TF on an isolated K = 2048 GEMM: the 256 tile halves the staging time but its LDS traffic -- DMA writes
-  // plus fragment reads -- no longer hides under the MFMAs).  Default 128; 256 stays selectable for probing.
-  (void)p;
+  if (forced == 128 || forced == 256 || forced == 512) return forced;
+  if (fwd_plain && p.N % 256 == 0 && ((p.M + 255) / 256) * (p.N / 256) >= 192) return 512;
   return 128;
 }
 
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
 int launch(const GemmParams& p, hipStream_t s) {
-  return pick_bm(p) == 256 ? launch_bm<T, TA, TB, ATOMIC, KA, KB, 256>(p, s) : launch_bm<T, TA, TB, ATOMIC, KA, KB, 128>(p, s);
+  switch (pick_tile(p, !TA && !TB && !ATOMIC && KA == 0 && KB == 0)) {
+    case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256>(p, s);
+    case 256: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 128>(p, s);
+    default: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 128, 128>(p, s);
+  }
 }
 
 inline int kind_class(int kind) { return kind == PT_V_CONV ? 1 : (kind == PT_V_WFLIP ? 2 : 0); }
