@@ -181,7 +181,7 @@ class ParamStore:
 # dgrad and wgrad of a layer both depend only on dy: the wgrad is issued on a second HIP stream so that it runs beside the
 # dgrad chain (the GEMMs are operand-latency bound, two resident kernels keep more loads in flight).  Its result is needed
 # only by the DP reducer / optimizer, which join the side stream first.
-WGRAD_SIDE_STREAM = True
+WGRAD_SIDE_STREAM = __import__("os").environ.get("PT_WGRAD_SIDE_STREAM", "1") != "0"
 _side = {}
 
 

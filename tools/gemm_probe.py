@@ -46,7 +46,56 @@ def run(lib, M, N, K, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def run_mode(lib, mode, tokens, n_out, k_in, split_k=1, iters=30):
+    """mode 'dgrad': dx[tokens,k_in] = dy[tokens,n_out] W[n_out,k_in];  'wgrad': gw[n_out,k_in] += dy^T x (f32 atomics)."""
+    dy = torch.randn(tokens, n_out, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(tokens, k_in, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(n_out, k_in, device="cuda", dtype=torch.bfloat16)
+    d = L.pt_gemm_desc()
+    if mode == "dgrad":
+        out = torch.empty(tokens, k_in, device="cuda", dtype=torch.bfloat16)
+        d.M, d.N, d.K = tokens, k_in, n_out
+        d.A.p, d.A.ld = dy.data_ptr(), n_out
+        d.B.p, d.B.ld, d.B.trans = w.data_ptr(), k_in, 1
+        d.C, d.ldc, d.split_k, d.alpha = out.data_ptr(), k_in, 1, 1.0
+    else:
+        out = torch.zeros(n_out, k_in, device="cuda", dtype=torch.float32)
+        d.M, d.N, d.K = n_out, k_in, tokens
+        d.A.p, d.A.ld, d.A.trans = dy.data_ptr(), n_out, 1
+        d.B.p, d.B.ld, d.B.trans = x.data_ptr(), k_in, 1
+        d.C, d.ldc, d.split_k, d.alpha, d.out_kind = out.data_ptr(), k_in, split_k, 1.0, L.PT_OUT_F32_ATOMIC
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        assert lib.pt_gemm(C.byref(d), 1, st) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.pt_gemm(C.byref(d), 1, st)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+BWD_SHAPES = [("lin 512<-512", 32768, 512, 512), ("qkv 1536<-512", 32768, 1536, 512), ("ff1 4096<-512", 32768, 4096, 512),
+              ("ff2 512<-2048", 32768, 512, 2048), ("lin T8192", 8192, 512, 512)]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--bwd":       # dgrad / wgrad shapes on the product library
+        lib = C.CDLL(L.LIB_PATH)
+        lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
+        import math
+        for name, T, NO, KI in BWD_SHAPES:
+            fl = 2.0 * T * NO * KI
+            us = run_mode(lib, "dgrad", T, NO, KI)
+            row = f"{name:16s} dgrad {us:8.1f} us {fl / us / 1e6:6.0f} TF |"
+            tiles = math.ceil(NO / 128) * math.ceil(KI / 128)
+            for tgt in (128, 256, 512, 1024):
+                sk = max(1, min(tgt // tiles, T // 64 // 4, 64))
+                us = run_mode(lib, "wgrad", T, NO, KI, sk)
+                row += f" wgrad sk{sk:<3d} {us:7.1f} us {fl / us / 1e6:5.0f} TF |"
+            print(row, flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--pmc":      # one shape on the product library, for rocprofv3 --pmc runs
         lib = C.CDLL(L.LIB_PATH)
         lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
