@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q image | dO image]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kblk = blockIdx.x * 128, k0 = kblk + wave * 32;
+  int b, h, blk;
+  attn_block_ids((p.Nk + 127) / 128, p.H, blk, h, b);
+  const int kblk = blk * 128, k0 = kblk + wave * 32;
   int nk = p.Nk;
   if (p.kv_len) { nk = p.kv_len[b]; nk = nk < 1 ? 1 : (nk > p.Nk ? p.Nk : nk); }
 
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K image | V image]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128, q0 = qblk + wave * 32;
+  int b, h, blk;
+  attn_block_ids((p.Nq + 127) / 128, p.H, blk, h, b);
+  const int qblk = blk * 128, q0 = qblk + wave * 32;
   int nk = p.Nk;
   if (p.kv_len) { nk = p.kv_len[b]; nk = nk < 1 ? 1 : (nk > p.Nk ? p.Nk : nk); }
   int klimit = nk;
@@ -313,8 +315,8 @@ template <typename T, int D> int launch_bwd(const AttnParams& p, hipStream_t s) 
   constexpr int CPR = D / (16 / (int)sizeof(T));
   const int64_t dthreads = (int64_t)p.B * p.Nq * p.H * CPR;
   hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)((dthreads + 255) / 256)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3((unsigned)((p.Nk + 127) / 128), (unsigned)p.H, (unsigned)p.B), dim3(256), lds_kv, s, p);
-  hipLaunchKernelGGL((attn_bwd_q_kernel<T, D>), dim3((unsigned)((p.Nq + 127) / 128), (unsigned)p.H, (unsigned)p.B), dim3(256), lds_q, s, p);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3((unsigned)(((p.Nk + 127) / 128) * p.H * p.B)), dim3(256), lds_kv, s, p);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<T, D>), dim3((unsigned)(((p.Nq + 127) / 128) * p.H * p.B)), dim3(256), lds_q, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }

@@ -23,6 +23,18 @@ struct AttnParams {
   char* dq; int64_t lddq; char* dk; int64_t lddk; char* dv; int64_t lddv;
 };
 
+// XCD-aware decode of a 1-D grid of nblk x H x B workgroups: ids congruent mod 8 share an XCD (round-robin dispatch), and
+// each XCD gets a contiguous run of (b, h, block) triples with the block index fastest, so the blocks of one (b, h) stream
+// the operand they all re-read (K/V for query blocks, Q/dO for key blocks) through ONE L2.  With the natural 3-D grid the 8
+// blocks of a (b, h) landed on 8 different XCDs and every L2 fetched every K/V: ~3x the fabric bytes (rocprofv3 FETCH_SIZE).
+__device__ __forceinline__ void attn_block_ids(int nblk, int H, int& blk, int& h, int& b) {
+  const int L = blockIdx.x, nwg = gridDim.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+  const int P = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+  blk = P % nblk;
+  const int bh = P / nblk;
+  h = bh % H; b = bh / H;
+}
+
 template <typename T, int D> struct AttnCfg {
   static constexpr int EPC = 16 / (int)sizeof(T);
   static constexpr int COLS = (D * (int)sizeof(T) >= 256) ? D : 256 / (int)sizeof(T);

@@ -13,8 +13,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K image | V image]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128, q0 = qblk + wave * 32;
+  int b, h, blk;
+  attn_block_ids((p.Nq + 127) / 128, p.H, blk, h, b);
+  const int qblk = blk * 128, q0 = qblk + wave * 32;
   int nk = p.Nk;
   if (p.kv_len) { nk = p.kv_len[b]; nk = nk < 1 ? 1 : (nk > p.Nk ? p.Nk : nk); }
   int klimit = nk;                                   // keys this workgroup has to visit
@@ -149,7 +150,9 @@ template <typename T, int D> int launch_fwd(const AttnParams& p, hipStream_t s) 
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PT_ERR_LAUNCH;
     attr_set = true;
   }
-  dim3 grid((unsigned)((p.Nq + 127) / 128), (unsigned)p.H, (unsigned)p.B);
+  const int64_t nwg = (int64_t)((p.Nq + 127) / 128) * p.H * p.B;
+  if (nwg >= (1ll << 31)) return PT_ERR_SHAPE;
+  dim3 grid((unsigned)nwg);
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(256), lds, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;

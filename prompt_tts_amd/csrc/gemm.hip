@@ -17,6 +17,7 @@
 //
 // Roofline: MFMA-bound for K >= 512 (2*128*128*K flops per 2*128*K*sizeof(T) operand bytes per tile).
 #include <stdlib.h>
+#include <type_traits>
 #include "mma.h"
 
 #ifndef PT_GEMM_ABLATE
@@ -98,178 +99,14 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
 }
 
 constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
-// Tile configurations (tools/gemm_probe.py: the kernel is bound by L2 -> LDS operand traffic, ~15 TB/s with 64 KB in
-// flight per CU, while the MFMA-only loop runs at ~1.2 PF; operand bytes per flop scale with 1/BM + 1/BN):
-//   128 x 128: 4 waves (2x2) of 64x64,  2 LDS stages,  72 KiB -> two workgroups per CU (small / few-tile problems)
-//   256 x 128: 8 waves (4x2) of 64x64,  3 LDS stages, 160 KiB -> counted s_waitcnt vmcnt + raw s_barrier, 2 tiles in flight
-//   256 x 256: 8 waves (2x4) of 128x64, 2 LDS stages, 144 KiB -> half the operand bytes per flop, 25 % fewer LDS
-//              fragment bytes per flop (128 accumulator registers per lane)
-template <int BM_, int BN_> struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_;
-  static constexpr int NWAVES = (BM_ == 128) ? 4 : 8, NTHREADS = 64 * NWAVES;
-  static constexpr int WAVES_N = BN_ / 64, WAVES_M = NWAVES / WAVES_N;
-  static constexpr int MI = BM_ / WAVES_M / 16, NJ = 4, WM = 16 * MI;      // per-wave tile WM x 64
-  static constexpr int NSTAGE = (BM_ == 256 && BN_ == 128) ? 3 : 2;
-  static constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int A_CHUNKS = BM_ * 8 / NTHREADS, B_CHUNKS = BN_ * 8 / NTHREADS;   // 16-byte chunks per thread per k-tile
-  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + NWAVES * SCRATCH_PER_WAVE;
-  static constexpr int MIN_WAVES_PER_SIMD = (BM_ == 128) ? 2 : 1;
-};
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
-__global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_WAVES_PER_SIMD)) void gemm_kernel(const GemmParams p) {
-  using Cfg = TileCfg<BM, BN>;
-  constexpr int NTHREADS = Cfg::NTHREADS, NSTAGE = Cfg::NSTAGE, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
-  constexpr int MI = Cfg::MI, WM = Cfg::WM;
-  constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
-  constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
-  constexpr int TCHA = BM / EPC, TCHB = BN / EPC;  // chunks per TileT row of the A / B image
-  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
-
-  if (PT_GEMM_ABLATE == 5) return;      // probe: pure dispatch cost
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;     // WAVES_M x WAVES_N waves of WM x 64
+// ---- epilogue (shared by both kernels): acc[i][j] is the 16x16 tile at rows 16 i, columns 16 j of the wave's
+// (16 MI) x 64 sub-tile whose origin is (m0 + wm * 16 MI, n0 + wn * 64); `scratch` = 2 KiB of wave-private LDS ----------
+template <typename T, bool ATOMIC, int MI, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], const int64_t m0, const int64_t n0,
+                                              const int wm, const int wn, const int lane, char* scratch) {
+  constexpr int WM = 16 * MI;
   const int g = lane >> 4, li = lane & 15;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
-  // run of tiles so neighbours that share an A row-panel hit the same L2.  Bijective for any grid size.
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-
-  const int nkt_total = (int)((p.K + BK - 1) / BK);
-  const int per = (nkt_total + p.split_k - 1) / p.split_k;
-  const int kt_begin = blockIdx.z * per;
-  const int kt_end = min(nkt_total, kt_begin + per);
-  if (kt_begin >= kt_end) return;
-
-  f32x4_t acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // One wave-instruction of global_load_lds writes 64 x 16 B = 1 KiB of LDS linearly (base + lane*16).  Chunk slot
-  // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
-  // data chunk (q%TCH)^swz(k): the swizzle lives in the SOURCE address.
-  const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
-  // Per-chunk source pointers live in registers and advance by a per-chunk byte step (0 for chunks parked on the zero
-  // page): 2 VALU per chunk per k-tile.  They are recomputed from scratch (vaddr) only when a countdown reaches zero:
-  // first k-tile, new conv tap / concat half, batch-item edges of a conv-wgrad operand, the K-tail tile.
-  // (PMC: the loop was instruction-issue bound -- MFMA pipes 17 % busy, ~225 instructions per k-tile per wave.)
-  const char* pa[Cfg::A_CHUNKS]; const char* pb[Cfg::B_CHUNKS];
-  uint32_t sta[Cfg::A_CHUNKS], stb[Cfg::B_CHUNKS];
-  const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
-  const int last_kt = nkt_total - 1;
-  const bool ktail = (p.K % BK) != 0;
-  int until_slow = 0;                           // k-tiles that may still take the fast path
-  auto fast_tiles_after = [&](int kt) {         // evaluated only on the slow path
-    auto dist = [&](const VOp& o) {
-      const int pos = kt % o.seg_kt;
-      int d = o.seg_kt - pos;
-      if (o.edge_slow) { if (pos == 0) d = 1; else if (pos < o.seg_kt - 1) d = min(d, o.seg_kt - 1 - pos); }
-      return d;
-    };
-    int d = min(dist(p.A), dist(p.B));
-    if (ktail && kt < last_kt) d = min(d, last_kt - kt);
-    return d - 1;
-  };
-  auto stage = [&](int kt, int stg) {
-    char* sa = smem + stg * STAGE_BYTES;
-    char* sb = sa + A_BYTES;
-    if (until_slow == 0) {
-      const int64_t k0 = (int64_t)kt * BK;
-#pragma unroll
-      for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
-        const int q = tid + NTHREADS * i;
-        if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHA; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
-        sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
-      }
-#pragma unroll
-      for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
-        const int q = tid + NTHREADS * i;
-        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHB; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
-        stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
-      }
-      until_slow = fast_tiles_after(kt);
-    } else {
-      --until_slow;
-#pragma unroll
-      for (int i = 0; i < Cfg::A_CHUNKS; ++i) pa[i] += sta[i];
-#pragma unroll
-      for (int i = 0; i < Cfg::B_CHUNKS; ++i) pb[i] += stb[i];
-    }
-    if (PT_GEMM_ABLATE == 2 || PT_GEMM_ABLATE == 4) return;
-#pragma unroll
-    for (int i = 0; i < Cfg::A_CHUNKS; ++i)
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + (wbase + NTHREADS * i) * 16), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < Cfg::B_CHUNKS; ++i)
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + (wbase + NTHREADS * i) * 16), 16, 0, 0);
-  };
-
-  auto compute = [&](int stg) {
-    const char* sa = smem + stg * STAGE_BYTES;
-    const char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < ((PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32); ++ks) {
-      Frag<T> fa[MI], fb[4];
-      const int kb = ks * 32 + 8 * g;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (!TA) frag_load_k(fa[i], sa, wm * WM + 16 * i + li, kb);
-        else     frag_load_t<BM>(fa[i], sa, wm * WM + 16 * i, kb, kb + 4, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (!TB) frag_load_k(fb[j], sb, wn * 64 + 16 * j + li, kb);
-        else     frag_load_t<BN>(fb[j], sb, wn * 64 + 16 * j, kb, kb + 4, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (ATOMIC) mma16(acc[i][j], fa[i], fb[j]);   // D[row = m][col = n]
-          else        mma16(acc[i][j], fb[j], fa[i]);   // D[row = n][col = m]: 4 consecutive n per lane
-        }
-    }
-  };
-  if (NSTAGE == 2) {
-    stage(kt_begin, 0);
-    __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
-      compute(cur);
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-    constexpr int PER_TILE = Cfg::A_CHUNKS + Cfg::B_CHUNKS;     // LDS-DMA instructions a thread issues per k-tile
-    stage(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      // retire k-tile kt (the younger one stays in flight), then rendezvous: every wave's pieces of kt have landed
-      // AND every wave is done reading the buffer that stage(kt + 2) overwrites
-      if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
-      compute(cur);
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-    __syncthreads();
-  }
-
-  if (PT_GEMM_ABLATE == 6) return;      // probe: everything but the epilogue code
-  // ---- epilogue ------------------------------------------------------------------------------------
   if (ATOMIC) {
     float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
@@ -299,7 +136,6 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   // residuals (vector loads).  Phase 2: activation + conversion, then the wave's 16 x 64 (bf16) / 16 x 32 (f32)
   // sub-tile goes through a wave-private XOR-swizzled LDS scratch and leaves as whole row segments, 16 B per lane.
   const bool out32 = sizeof(T) == 4 || p.out_kind == PT_OUT_F32;
-  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE;
   // Fast path (interior tile, bf16 output, 16-byte aligned rows): no per-element predicates at all.  The generic
   // path below costs ~2500 executed instructions per wave -- as much as the MFMA work of a K = 512 tile.
   if (sizeof(T) == 2 && !out32 && PT_GEMM_ABLATE != 3 && PT_GEMM_ABLATE != 4 && m0 + BM <= p.M && n0 + BN <= p.N &&
@@ -477,6 +313,384 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   }
 }
 
+// Tile configurations (tools/gemm_probe.py: the kernel is bound by L2 -> LDS operand traffic, ~15 TB/s with 64 KB in
+// flight per CU, while the MFMA-only loop runs at ~1.2 PF; operand bytes per flop scale with 1/BM + 1/BN):
+//   128 x 128: 4 waves (2x2) of 64x64,  2 LDS stages,  72 KiB -> two workgroups per CU (small / few-tile problems)
+//   256 x 128: 8 waves (4x2) of 64x64,  3 LDS stages, 160 KiB -> counted s_waitcnt vmcnt + raw s_barrier, 2 tiles in flight
+//   256 x 256: 8 waves (2x4) of 128x64, 2 LDS stages, 144 KiB -> half the operand bytes per flop, 25 % fewer LDS
+//              fragment bytes per flop (128 accumulator registers per lane)
+template <int BM_, int BN_> struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_;
+  static constexpr int NWAVES = (BM_ == 128) ? 4 : 8, NTHREADS = 64 * NWAVES;
+  static constexpr int WAVES_N = BN_ / 64, WAVES_M = NWAVES / WAVES_N;
+  static constexpr int MI = BM_ / WAVES_M / 16, NJ = 4, WM = 16 * MI;      // per-wave tile WM x 64
+  static constexpr int NSTAGE = (BM_ == 256 && BN_ == 128) ? 3 : 2;
+  static constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_CHUNKS = BM_ * 8 / NTHREADS, B_CHUNKS = BN_ * 8 / NTHREADS;   // 16-byte chunks per thread per k-tile
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + NWAVES * SCRATCH_PER_WAVE;
+  static constexpr int MIN_WAVES_PER_SIMD = (BM_ == 128) ? 2 : 1;
+};
+
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
+__global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_WAVES_PER_SIMD)) void gemm_kernel(const GemmParams p) {
+  using Cfg = TileCfg<BM, BN>;
+  constexpr int NTHREADS = Cfg::NTHREADS, NSTAGE = Cfg::NSTAGE, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int MI = Cfg::MI, WM = Cfg::WM;
+  constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
+  constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
+  constexpr int TCHA = BM / EPC, TCHB = BN / EPC;  // chunks per TileT row of the A / B image
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+
+  if (PT_GEMM_ABLATE == 5) return;      // probe: pure dispatch cost
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;     // WAVES_M x WAVES_N waves of WM x 64
+  const int g = lane >> 4, li = lane & 15;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
+  // run of tiles so neighbours that share an A row-panel hit the same L2.  Bijective for any grid size.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // grid.x = tiles x split_k, K-slice major: the run of ids an XCD owns is (nearly) one K-slice of every tile, so a split-K
+  // wgrad streams each operand through one L2 once (tile-major slices made every XCD re-fetch whole panels: 3x the bytes)
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int kslice = bid / ntile, tix = bid - kslice * ntile;
+  const int tm = tix / p.tiles_n, tn = tix - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int nkt_total = (int)((p.K + BK - 1) / BK);
+  const int per = (nkt_total + p.split_k - 1) / p.split_k;
+  const int kt_begin = kslice * per;
+  const int kt_end = min(nkt_total, kt_begin + per);
+  if (kt_begin >= kt_end) return;
+
+  f32x4_t acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // One wave-instruction of global_load_lds writes 64 x 16 B = 1 KiB of LDS linearly (base + lane*16).  Chunk slot
+  // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
+  // data chunk (q%TCH)^swz(k): the swizzle lives in the SOURCE address.
+  const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
+  // Per-chunk source pointers live in registers and advance by a per-chunk byte step (0 for chunks parked on the zero
+  // page): 2 VALU per chunk per k-tile.  They are recomputed from scratch (vaddr) only when a countdown reaches zero:
+  // first k-tile, new conv tap / concat half, batch-item edges of a conv-wgrad operand, the K-tail tile.
+  // (PMC: the loop was instruction-issue bound -- MFMA pipes 17 % busy, ~225 instructions per k-tile per wave.)
+  const char* pa[Cfg::A_CHUNKS]; const char* pb[Cfg::B_CHUNKS];
+  uint32_t sta[Cfg::A_CHUNKS], stb[Cfg::B_CHUNKS];
+  const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
+  const int last_kt = nkt_total - 1;
+  const bool ktail = (p.K % BK) != 0;
+  int until_slow = 0;                           // k-tiles that may still take the fast path
+  auto fast_tiles_after = [&](int kt) {         // evaluated only on the slow path
+    auto dist = [&](const VOp& o) {
+      const int pos = kt % o.seg_kt;
+      int d = o.seg_kt - pos;
+      if (o.edge_slow) { if (pos == 0) d = 1; else if (pos < o.seg_kt - 1) d = min(d, o.seg_kt - 1 - pos); }
+      return d;
+    };
+    int d = min(dist(p.A), dist(p.B));
+    if (ktail && kt < last_kt) d = min(d, last_kt - kt);
+    return d - 1;
+  };
+  auto stage = [&](int kt, int stg) {
+    char* sa = smem + stg * STAGE_BYTES;
+    char* sb = sa + A_BYTES;
+    if (until_slow == 0) {
+      const int64_t k0 = (int64_t)kt * BK;
+#pragma unroll
+      for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
+        const int q = tid + NTHREADS * i;
+        if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHA; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
+        sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
+      }
+#pragma unroll
+      for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
+        const int q = tid + NTHREADS * i;
+        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHB; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
+        stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
+      }
+      until_slow = fast_tiles_after(kt);
+    } else {
+      --until_slow;
+#pragma unroll
+      for (int i = 0; i < Cfg::A_CHUNKS; ++i) pa[i] += sta[i];
+#pragma unroll
+      for (int i = 0; i < Cfg::B_CHUNKS; ++i) pb[i] += stb[i];
+    }
+    if (PT_GEMM_ABLATE == 2 || PT_GEMM_ABLATE == 4) return;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i)
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + (wbase + NTHREADS * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i)
+      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + (wbase + NTHREADS * i) * 16), 16, 0, 0);
+  };
+
+  auto compute = [&](int stg) {
+    const char* sa = smem + stg * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < ((PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32); ++ks) {
+      Frag<T> fa[MI], fb[4];
+      const int kb = ks * 32 + 8 * g;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (!TA) frag_load_k(fa[i], sa, wm * WM + 16 * i + li, kb);
+        else     frag_load_t<BM>(fa[i], sa, wm * WM + 16 * i, kb, kb + 4, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!TB) frag_load_k(fb[j], sb, wn * 64 + 16 * j + li, kb);
+        else     frag_load_t<BN>(fb[j], sb, wn * 64 + 16 * j, kb, kb + 4, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ATOMIC) mma16(acc[i][j], fa[i], fb[j]);   // D[row = m][col = n]
+          else        mma16(acc[i][j], fb[j], fa[i]);   // D[row = n][col = m]: 4 consecutive n per lane
+        }
+    }
+  };
+  if (NSTAGE == 2) {
+    stage(kt_begin, 0);
+    __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    constexpr int PER_TILE = Cfg::A_CHUNKS + Cfg::B_CHUNKS;     // LDS-DMA instructions a thread issues per k-tile
+    stage(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      // retire k-tile kt (the younger one stays in flight), then rendezvous: every wave's pieces of kt have landed
+      // AND every wave is done reading the buffer that stage(kt + 2) overwrites
+      if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+      compute(cur);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();
+  }
+
+  if (PT_GEMM_ABLATE == 6) return;      // probe: everything but the epilogue code
+  gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE);
+}
+
+// =====================================================================================================================
+// 256 x 256 "eight-phase" kernel (bf16): the deep-pipelined variant for problems with at least a round of 256x256 tiles.
+// The 2-stage loop above has every load of k-tile t+1 issued at once and drained (vmcnt(0)) one MFMA block later: bytes in
+// flight collapse to zero around every barrier, and the loop runs at load latency + transfer time.  Here a k-tile is
+// staged as four 16 KiB UNITS -- a0/a1 = the first/second 64 rows of each wave-row's 128-row A panel, b0/b1 = the first /
+// second 32 columns of each wave-column's 64-column B panel -- consumed one output quadrant per phase:
+//     phase 0: (a0,b0)   phase 1: (a0,b1)   phase 2: (a1,b1)   phase 3: (a1,b0; b0 stays in registers)
+// so a unit's LDS is dead two phases after its last read and is restaged with the k-tile two ahead while the current one
+// is still being multiplied: 4-5 units (64-80 KiB) are in flight at all times, retired by COUNTED s_waitcnt vmcnt(N)
+// (never 0 in the steady state) in front of raw s_barriers.
+//     issue order:  tile t phase 0: a1(t+1)   1: b1(t+1)   2: a0(t+2)   3: b0(t+2)
+//     waits:        end of phase 3: vmcnt(8) retires a0,b0(t+1);   end of phase 0: vmcnt(6) retires a1,b1(t)
+// Each phase = {fragment reads + one unit's LDS-DMA} barrier {16 MFMA} barrier, and the two wave-rows run one barrier
+// apart (the wr = 1 waves take one extra barrier up front, wr = 0 one at the end): on every SIMD one wave multiplies while
+// the other reads LDS / issues loads.  Hazards with that stagger: a unit is restaged >= 2 phases after its last ds_read,
+// and read >= 1 phase after the wait that retires it.
+// Unit images are TileK ([128 rows][128 B]) or TileT<128> ([64 k][256 B]) exactly as in the kernel above, so every
+// operand kind / transposition goes through the same vaddr() and fragment loaders.
+// =====================================================================================================================
+constexpr int P8_UNIT = 16384, P8_BUF = 4 * P8_UNIT, P8_THREADS = 512;
+
+template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams p) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 256, BK = 64, EPC = 8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];     // the ONLY LDS object (epilogue scratch aliases it)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, li = lane & 15;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // grid.x = tiles x split_k, K-slice major: the run of ids an XCD owns is (nearly) one K-slice of every tile, so a split-K
+  // wgrad streams each operand through one L2 once (tile-major slices made every XCD re-fetch whole panels: 3x the bytes)
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int kslice = bid / ntile, tix = bid - kslice * ntile;
+  const int tm = tix / p.tiles_n, tn = tix - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int nkt_total = (int)((p.K + BK - 1) / BK);
+  const int per = (nkt_total + p.split_k - 1) / p.split_k;
+  const int kt_begin = kslice * per;
+  const int kt_end = min(nkt_total, kt_begin + per);
+  if (kt_begin >= kt_end) return;                    // whole workgroup: no barrier has been executed yet
+  const int nt = kt_end - kt_begin;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging state: unit U = 2 * operand + half; two 16-byte chunks per thread per unit ----
+  const char* ptr[4][2]; uint32_t stp[4][2]; int cnt[4] = {0, 0, 0, 0};
+  const char* zero_page = reinterpret_cast<const char*>(pt_zero_page);
+  const int last_kt = nkt_total - 1;
+  const bool ktail = (p.K % BK) != 0;
+  auto fast_tiles_after = [&](const VOp& o, int kt) {
+    const int pos = kt % o.seg_kt;
+    int d = o.seg_kt - pos;
+    if (o.edge_slow) { if (pos == 0) d = 1; else if (pos < o.seg_kt - 1) d = min(d, o.seg_kt - 1 - pos); }
+    if (ktail && kt < last_kt) d = min(d, last_kt - kt);
+    return d - 1;
+  };
+  const int wbase = wave * 64;
+  // unit-local index -> tile row (A) / tile column (B): u = (wave-row or wave-col) * (64 | 32) + offset
+  auto stage = [&](auto oper_c, auto half_c, int kt, char* buf) {
+    constexpr int OPER = decltype(oper_c)::value, S = decltype(half_c)::value, U = 2 * OPER + S;
+    constexpr bool TR = OPER == 0 ? TA : TB;
+    constexpr int KC = OPER == 0 ? KA : KB;
+    const VOp& op = OPER == 0 ? p.A : p.B;
+    const int64_t t0 = OPER == 0 ? m0 : n0;
+    char* dst = buf + U * P8_UNIT;
+    if (cnt[U] == 0) {
+      const int64_t k0 = (int64_t)kt * BK;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = tid + P8_THREADS * i;
+        if (!TR) {
+          const int u = q >> 3, c = (q & 7) ^ (u & 7);
+          const int trow = OPER == 0 ? ((u >> 6) * 128 + S * 64 + (u & 63)) : ((u >> 5) * 64 + S * 32 + (u & 31));
+          ptr[U][i] = vaddr<T, KC>(op, t0 + trow, k0 + c * EPC);
+        } else {
+          const int k = q >> 4, uc = ((q & 15) ^ tilet_swz(k)) * EPC;
+          const int tcol = OPER == 0 ? ((uc >> 6) * 128 + S * 64 + (uc & 63)) : ((uc >> 5) * 64 + S * 32 + (uc & 31));
+          ptr[U][i] = vaddr<T, KC>(op, k0 + k, t0 + tcol);
+        }
+        stp[U][i] = ptr[U][i] == zero_page ? 0u : (uint32_t)op.step;
+      }
+      cnt[U] = fast_tiles_after(op, kt);
+    } else {
+      --cnt[U];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ptr[U][i] += stp[U][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((pt_gptr*)ptr[U][i], (pt_lptr*)(dst + (wbase + P8_THREADS * i) * 16), 16, 0, 0);
+  };
+  using std::integral_constant;
+  integral_constant<int, 0> OA, H0; integral_constant<int, 1> OB, H1;
+
+  Frag<T> fa[4][2], fb0[2][2], fb1[2][2];
+  auto read_a = [&](const char* buf, int s) {
+    const char* img = buf + s * P8_UNIT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kb = ks * 32 + 8 * g;
+        if (!TA) frag_load_k(fa[i][ks], img, wr * 64 + 16 * i + li, kb);
+        else     frag_load_t<128>(fa[i][ks], img, wr * 64 + 16 * i, kb, kb + 4, lane);
+      }
+  };
+  auto read_b = [&](Frag<T> (&fb)[2][2], const char* buf, int s) {
+    const char* img = buf + (2 + s) * P8_UNIT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kb = ks * 32 + 8 * g;
+        if (!TB) frag_load_k(fb[j][ks], img, wc * 32 + 16 * j + li, kb);
+        else     frag_load_t<128>(fb[j][ks], img, wc * 32 + 16 * j, kb, kb + 4, lane);
+      }
+  };
+  // one output quadrant: rows 64 sa .. +63, columns 32 sb .. +31 of the wave's 128 x 64 tile, over the whole k-tile
+  auto quadrant = [&](auto sa_c, auto sb_c, const Frag<T> (&fb)[2][2]) {
+    constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (ATOMIC) mma16(acc[4 * SA + i][2 * SB + j], fa[i][ks], fb[j][ks]);   // D[row = m][col = n]
+          else        mma16(acc[4 * SA + i][2 * SB + j], fb[j][ks], fa[i][ks]);   // D[row = n][col = m]
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+#define P8_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  // HAS1 / HAS2: k-tiles t+1 / t+2 exist (the last two tiles of the range issue fewer units, so their counts differ)
+  auto tile = [&](auto has1_c, auto has2_c, int kt, char* cur, char* nxt) {
+    constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has2_c)::value;
+    // phase 0
+    read_b(fb0, cur, 0); __builtin_amdgcn_sched_barrier(0); read_a(cur, 0);
+    if (HAS1) { stage(OA, H1, kt + 1, nxt); P8_VMCNT(6); } else { P8_VMCNT(0); }
+    quadrant(H0, H0, fb0);
+    // phase 1
+    read_b(fb1, cur, 1);
+    if (HAS1) stage(OB, H1, kt + 1, nxt);
+    quadrant(H0, H1, fb1);
+    // phase 2
+    read_a(cur, 1);
+    if (HAS2) stage(OA, H0, kt + 2, cur);
+    quadrant(H1, H1, fb1);
+    // phase 3
+    if (HAS2) { stage(OB, H0, kt + 2, cur); P8_VMCNT(8); } else if (HAS1) { P8_VMCNT(4); }
+    quadrant(H1, H0, fb0);
+  };
+  integral_constant<bool, true> YES; integral_constant<bool, false> NO;
+
+  // ---- prologue: a0,b0,a1,b1 of the first k-tile, a0,b0 of the second ----
+  stage(OA, H0, kt_begin, smem); stage(OB, H0, kt_begin, smem);
+  stage(OA, H1, kt_begin, smem); stage(OB, H1, kt_begin, smem);
+  if (nt > 1) { stage(OA, H0, kt_begin + 1, smem + P8_BUF); stage(OB, H0, kt_begin + 1, smem + P8_BUF); P8_VMCNT(8); }
+  else { P8_VMCNT(4); }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger the wave-rows by one barrier
+
+  int lt = 0;
+  for (; lt + 2 < nt; ++lt) {
+    char* cur = smem + (lt & 1) * P8_BUF; char* nxt = smem + ((lt & 1) ^ 1) * P8_BUF;
+    tile(YES, YES, kt_begin + lt, cur, nxt);
+  }
+  if (lt + 1 < nt) {
+    char* cur = smem + (lt & 1) * P8_BUF; char* nxt = smem + ((lt & 1) ^ 1) * P8_BUF;
+    tile(YES, NO, kt_begin + lt, cur, nxt);
+    ++lt;
+  }
+  {
+    char* cur = smem + (lt & 1) * P8_BUF; char* nxt = smem + ((lt & 1) ^ 1) * P8_BUF;
+    tile(NO, NO, kt_begin + lt, cur, nxt);
+  }
+#undef P8_VMCNT
+  if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align: every wave has finished its LDS reads past this point
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * SCRATCH_PER_WAVE);
+}
+
 VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
   VOp v;
   v.p = reinterpret_cast<const char*>(o.p); v.p2 = reinterpret_cast<const char*>(o.p2);
@@ -530,28 +744,42 @@ int check_operand(const pt_operand& o, int esize) {
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
 int launch_cfg(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
-  if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
-  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
+  if ((int64_t)p.tiles_m * p.tiles_n * p.split_k >= (1ll << 31)) return PT_ERR_SHAPE;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, 1);
   hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM, BN>), grid, dim3(TileCfg<BM, BN>::NTHREADS), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
 
-// Tile choice; PT_GEMM_TILE=128|256|512 (= 128x128 | 256x128 | 256x256) overrides it for A/B probing (tools/gemm_probe.py).
-// Measured on the training step (config B): 256x256 wins for the forward linears (650-1040 TF isolated vs 550-910) but
-// its transposed-operand variants spill and the wgrads have too few tiles for it, so it is used for forward plain GEMMs
-// with at least one full round of 256x256 tiles; everything else runs 128x128 with two workgroups per CU.
-inline int pick_tile(const GemmParams& p, bool fwd_plain) {
-  static int forced = -1;
+// Tile choice.  PT_GEMM_TILE=128|256|512|8 (= 128x128 | 256x128 | 256x256 two-stage | 256x256 eight-phase) forces one
+// configuration for A/B probing (tools/gemm_probe.py); PT_GEMM_8P_MASK selects which GEMM classes may use the eight-phase
+// kernel (bit 0 forward plain, 1 dgrad plain, 2 conv forward, 3 conv dgrad, 4 wgrad).
+inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
+  static int forced = -1, mask = -1;
   if (forced < 0) { const char* e = getenv("PT_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-  if (forced == 128 || forced == 256 || forced == 512) return forced;
-  if (fwd_plain && p.N % 256 == 0 && ((p.M + 255) / 256) * (p.N / 256) >= 192) return 512;
+  if (mask < 0) { const char* e = getenv("PT_GEMM_8P_MASK"); mask = e ? atoi(e) : 0x0f; }
+  if (forced == 128 || forced == 256 || forced == 512 || forced == 8) return forced;
+  const int64_t tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.split_k;
+  if (bf16 && ((mask >> cls) & 1) && tiles256 >= 192) return 8;
   return 128;
+}
+
+template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
+int launch_8p(GemmParams p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (int)((p.N + 255) / 256);
+  if ((int64_t)p.tiles_m * p.tiles_n * p.split_k >= (1ll << 31)) return PT_ERR_SHAPE;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, 1);
+  hipLaunchKernelGGL((gemm8p_kernel<TA, TB, ATOMIC, KA, KB>), grid, dim3(P8_THREADS), 0, s, p);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
 }
 
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
 int launch(const GemmParams& p, hipStream_t s) {
-  switch (pick_tile(p, !TA && !TB && !ATOMIC && KA == 0 && KB == 0)) {
+  constexpr int cls = ATOMIC ? 4 : (!TB ? (KA == 0 ? 0 : 2) : (KA == 0 ? 1 : 3));
+  const int tile = pick_tile(p, cls, sizeof(T) == 2);
+  if constexpr (sizeof(T) == 2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB>(p, s); }
+  switch (tile) {
     case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256>(p, s);
     case 256: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 128>(p, s);
     default: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 128, 128>(p, s);
