@@ -183,6 +183,7 @@ class ParamStore:
 # only by the DP reducer / optimizer, which join the side stream first.
 WGRAD_SIDE_STREAM = __import__("os").environ.get("PT_WGRAD_SIDE_STREAM", "1") != "0"
 _side = {}
+_DIAG_SKIP_WGRAD = __import__("os").environ.get("PT_DIAG_SKIP_WGRAD", "0") == "1"
 
 
 def _side_stream(device):
@@ -194,6 +195,8 @@ def _side_stream(device):
 
 def on_side_stream(fn, *tensors):
     """Run fn() (kernel launches reading `tensors`) on the wgrad side stream, ordered after the current stream."""
+    if _DIAG_SKIP_WGRAD:                 # timing diagnostic only (wrong gradients): the main-stream chain by itself
+        return
     if not WGRAD_SIDE_STREAM:
         fn()
         return
@@ -254,6 +257,16 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
     on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
+    if (M <= 128 and N >= 2048 and M % 4 == 0 and x.dtype == torch.float32 and dx_out is None and dx_accum is None
+            and dx_residual is None):
+        # skinny dgrad (the batched time-embedding projection: 32 rows, reduction over every resnet's channels): as
+        # dx[M][K] it is 4 output tiles walking the whole reduction serially (0.5 ms); as dx^T = W^T dy^T it is a split-K
+        # GEMM over the chip
+        dy_t = dy.t().contiguous()
+        dxt = torch.zeros(K, M, dtype=torch.float32, device=x.device)
+        ops.gemm(K, M, N, ops.plain(w, trans=True), ops.plain(dy_t, trans=True), dxt, pt, ldc=M,
+                 out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(K, M, N, x.dtype))
+        return dxt.t().contiguous()
     dx = dx_out if dx_out is not None else (dx_accum if dx_accum is not None else _empty(M, K, x))
     res2 = dx_accum
     ops.gemm(M, K, N, ops.plain(dy), ops.plain(w, trans=True), dx, pt, ldc=dx.stride(0),
