@@ -133,18 +133,23 @@ int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const flo
                      int64_t M, int64_t C, int dtype, pt_stream stream);
 
 /* nn.GroupNorm(G, C, eps) [+ SiLU] on token-major x = concat(x1[B][N][C1], x2[B][N][C2]) (x2 may be NULL)
- * (tts/ldm/resnet.py:238-240,267-273; transformer_1d.py:251; unet_1d_condition.py:731-733). */
+ * (tts/ldm/resnet.py:238-240,267-273; transformer_1d.py:251; unet_1d_condition.py:731-733).
+ * Statistics come in two forms.  Finalized: pt_groupnorm_stats(eps >= 0) zeroes mean/rstd, accumulates and finalizes them
+ * (3 extra launches).  Raw: pt_groupnorm_stats(eps < 0) only ADDS the per-(batch, group) sum / sum of squares into
+ * mean[] / rstd[], which the caller zeroed (e.g. one arena memset per step); apply / bwd are then given raw_eps = eps >= 0
+ * and finalize on the fly (raw_eps < 0: the arrays hold finalized statistics). */
 int pt_groupnorm_stats(const void* x1, const void* x2, float* mean, float* rstd,
                        int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, float eps, int dtype, pt_stream stream);
 int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, void* y, void* xcat /* raw concat copy or NULL */,
-                       int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int dtype, pt_stream stream);
-/* backward: ws = f32 [B][G][2] scratch (zeroed by the call).  dx1/dx2 = GN'(dy) [+ dres (concat layout)]. */
+                       int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, float raw_eps, int dtype,
+                       pt_stream stream);
+/* backward: ws = f32 [B][G][2] scratch (zeroed by the call unless ws_zeroed).  dx1/dx2 = GN'(dy) [+ dres (concat layout)]. */
 int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                      float* dgamma, float* dbeta, float* ws,
                      int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int accumulate_dx2,
-                     int dtype, pt_stream stream);
+                     float raw_eps, int ws_zeroed, int dtype, pt_stream stream);
 
 /* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F]. */
 int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream);

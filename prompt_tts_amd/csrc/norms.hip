@@ -135,7 +135,19 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
 // GroupNorm on x = concat(x1[B][N][C1], x2[B][N][C2]) (token-major).  A block owns (batch b, a run of rows);
 // thread (cw, rr) owns column chunks cw + j*CW and rows rr, rr+RP, ...
 // ---------------------------------------------------------------------------------------------------
-struct GnGeom { int C1, C2, C, CC, CW, RP, J, G, cpg, N, rows_per_block; };
+struct GnGeom { int C1, C2, C, CC, CW, RP, J, G, cpg, N, rows_per_block; float raw_cnt, eps; };
+
+// per-(batch, group) statistics: either finalized (mean, rstd) or -- raw_cnt > 0 -- the raw (sum, sum of squares) the
+// stats kernel accumulated, finalized here by every consumer (same arithmetic as gn_finalize_kernel; saves a launch)
+__device__ __forceinline__ void gn_stat(const float* __restrict__ mean, const float* __restrict__ rstd, int idx, const GnGeom& g,
+                                        float& mu, float& rs) {
+  mu = mean[idx]; rs = rstd[idx];
+  if (g.raw_cnt > 0.f) {
+    mu = mu / g.raw_cnt;
+    const float var = fmaxf(rs / g.raw_cnt - mu * mu, 0.f);
+    rs = rsqrtf(var + g.eps);
+  }
+}
 
 template <typename T> __device__ __forceinline__ const T* gn_src(const T* x1, const T* x2, const GnGeom& g, int64_t row, int col) {
   return col < g.C1 ? x1 + row * g.C1 + col : x2 + row * g.C2 + (col - g.C1);
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x1, 
       sc[j][e] = 0.f; sf[j][e] = 0.f;
       if (j < g.J && c < g.CC) {
         const int col = c * EPC + e, grp = col / g.cpg;
-        const float mu = mean[b * g.G + grp], rs = rstd[b * g.G + grp];
+        float mu, rs; gn_stat(mean, rstd, b * g.G + grp, g, mu, rs);
         sc[j][e] = rs * gamma[col];
         sf[j][e] = beta[col] - mu * rs * gamma[col];
       }
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ d
       mu[j][e] = 0.f; rs[j][e] = 0.f; ga[j][e] = 0.f; be[j][e] = 0.f; sg[j][e] = 0.f; sb[j][e] = 0.f;
       if (j < g.J && c < g.CC) {
         const int col = c * EPC + e, grp = col / g.cpg;
-        mu[j][e] = mean[b * g.G + grp]; rs[j][e] = rstd[b * g.G + grp];
+        gn_stat(mean, rstd, b * g.G + grp, g, mu[j][e], rs[j][e]);
         ga[j][e] = gamma[col]; be[j][e] = beta[col];
       }
     }
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
       mu[j][e] = rs[j][e] = ga[j][e] = be[j][e] = mA[j][e] = mB[j][e] = 0.f;
       if (j < g.J && c < g.CC) {
         const int col = c * EPC + e, grp = col / g.cpg;
-        mu[j][e] = mean[b * g.G + grp]; rs[j][e] = rstd[b * g.G + grp];
+        gn_stat(mean, rstd, b * g.G + grp, g, mu[j][e], rs[j][e]);
         ga[j][e] = gamma[col]; be[j][e] = beta[col];
         mA[j][e] = ws[((int64_t)b * g.G + grp) * 2] * inv_cnt;
         mB[j][e] = ws[((int64_t)b * g.G + grp) * 2 + 1] * inv_cnt;
@@ -401,6 +413,7 @@ template <typename T> int gn_geom(GnGeom& g, int64_t N, int64_t C1, int64_t C2, 
   g.J = (g.CC + g.CW - 1) / g.CW;
   if (g.J > 2) return PT_ERR_SHAPE;
   g.rows_per_block = 64;
+  g.raw_cnt = 0.f; g.eps = 0.f;
   return PT_OK;
 }
 
@@ -458,12 +471,17 @@ template <typename T>
 static int gn_stats_t(const void* x1, const void* x2, float* mean, float* rstd, int64_t B, int64_t N, int64_t C1,
                       int64_t C2, int64_t G, float eps, hipStream_t s) {
   GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
-  if (hipMemsetAsync(mean, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
-  if (hipMemsetAsync(rstd, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
+  const bool raw = eps < 0.f;               // raw mode: accumulate (sum, sumsq) into caller-zeroed arrays, no finalize
+  if (!raw) {
+    if (hipMemsetAsync(mean, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
+    if (hipMemsetAsync(rstd, 0, sizeof(float) * B * G, s) != hipSuccess) return PT_ERR_LAUNCH;
+  }
   dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
   hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(NT), 0, s, (const T*)x1, (const T*)x2, mean, rstd, g);
-  const int n = (int)(B * G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mean, rstd, n, (float)N * (float)g.cpg, eps);
+  if (!raw) {
+    const int n = (int)(B * G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mean, rstd, n, (float)N * (float)g.cpg, eps);
+  }
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
@@ -481,8 +499,9 @@ extern "C" int pt_groupnorm_stats(const void* x1, const void* x2, float* mean, f
 template <typename T>
 static int gn_apply_t(const void* x1, const void* x2, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, void* y, void* xcat, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G,
-                      int silu, hipStream_t s) {
+                      int silu, float raw_eps, hipStream_t s) {
   GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
+  if (raw_eps >= 0.f) { g.raw_cnt = (float)N * (float)g.cpg; g.eps = raw_eps; }
   dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
   hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(NT), 0, s, (const T*)x1, (const T*)x2, mean, rstd, gamma, beta,
                      (T*)y, (T*)xcat, g, silu);
@@ -492,12 +511,12 @@ static int gn_apply_t(const void* x1, const void* x2, const float* mean, const f
 
 extern "C" int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, void* y, void* xcat, int64_t B, int64_t N,
-                                  int64_t C1, int64_t C2, int64_t G, int silu, int dtype, pt_stream stream) {
+                                  int64_t C1, int64_t C2, int64_t G, int silu, float raw_eps, int dtype, pt_stream stream) {
   if (B <= 0 || (C2 > 0 && !x2)) return PT_ERR_SHAPE;
   if (!pt_aligned16(x1) || (x2 && !pt_aligned16(x2)) || !pt_aligned16(y) || (xcat && !pt_aligned16(xcat))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32) return gn_apply_t<float>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, s);
-  if (dtype == PT_BF16) return gn_apply_t<bf16_t>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, s);
+  if (dtype == PT_F32) return gn_apply_t<float>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, raw_eps, s);
+  if (dtype == PT_BF16) return gn_apply_t<bf16_t>(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, C1, C2, G, silu, raw_eps, s);
   return PT_ERR_DTYPE;
 }
 
@@ -505,9 +524,10 @@ template <typename T>
 static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2, float* dgamma,
                     float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu,
-                    int acc_dx2, hipStream_t s) {
+                    int acc_dx2, float raw_eps, int ws_zeroed, hipStream_t s) {
   GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
-  if (hipMemsetAsync(ws, 0, sizeof(float) * B * G * 2, s) != hipSuccess) return PT_ERR_LAUNCH;
+  if (raw_eps >= 0.f) { g.raw_cnt = (float)N * (float)g.cpg; g.eps = raw_eps; }
+  if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(float) * B * G * 2, s) != hipSuccess) return PT_ERR_LAUNCH;
   dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
   const size_t dyn = sizeof(float) * (2 * (size_t)g.C + 2 * (size_t)g.G);
   hipLaunchKernelGGL((gn_bwd_sums_kernel<T>), grid, dim3(NT), dyn, s, (const T*)dy, (const T*)x1, (const T*)x2, mean,
@@ -521,12 +541,13 @@ static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float*
 extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                                 float* dgamma, float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2,
-                                int64_t G, int silu, int accumulate_dx2, int dtype, pt_stream stream) {
+                                int64_t G, int silu, int accumulate_dx2, float raw_eps, int ws_zeroed, int dtype,
+                                pt_stream stream) {
   if (B <= 0 || (C2 > 0 && (!x2 || !dx2))) return PT_ERR_SHAPE;
   if (!pt_aligned16(dy) || !pt_aligned16(x1) || !pt_aligned16(dx1) || (x2 && !pt_aligned16(x2)) ||
       (dx2 && !pt_aligned16(dx2)) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, s);
-  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, s);
+  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, s);
+  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, s);
   return PT_ERR_DTYPE;
 }

@@ -80,6 +80,8 @@ class ParamStore:
             arr[i].offset, arr[i].numel, arr[i].shadow_offset, arr[i].layout, arr[i].cin, arr[i].cin_pad, arr[i].frozen = s
         raw = bytes(arr)
         self.seg_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.arena = None               # ZeroArena, created on first fused step
+        self.arena_active = None        # set by the fused loss+backward path only (forward and backward are one episode)
         with torch.no_grad():
             for p in self.params:
                 i = self.info[id(p)]
@@ -327,25 +329,57 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
 
 
 class GNState:
-    __slots__ = ("mean", "rstd")
+    __slots__ = ("mean", "rstd", "raw_eps")
 
 
-def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu):
+class ZeroArena:
+    """f32 scratch that is zero when handed out: ONE memset per training step (reset()) replaces a memset per GroupNorm
+    statistics / workspace buffer (3 launches per GroupNorm forward+backward, ~180 per step)."""
+
+    def __init__(self, device, n_floats=1 << 20):
+        self.buf = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        self.off = 0
+        self.dirty = False
+
+    def reset(self):
+        if self.dirty:
+            self.buf[:self.off].zero_()
+        self.off = 0
+        self.dirty = False
+
+    def alloc(self, n):
+        n_al = (n + 63) // 64 * 64
+        if self.off + n_al > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=self.buf.device)
+        out = self.buf[self.off:self.off + n]
+        self.off += n_al
+        self.dirty = True
+        return out
+
+
+def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu, arena=None):
     C = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     s = GNState()
-    s.mean = torch.empty(B * G, dtype=torch.float32, device=x1.device)
-    s.rstd = torch.empty(B * G, dtype=torch.float32, device=x1.device)
-    ops.groupnorm_stats(x1, x2, s.mean, s.rstd, B, N, G, eps)
     y = _empty(B * N, C, x1)
-    ops.groupnorm_apply(x1, x2, s.mean, s.rstd, gamma, beta, y, None, B, N, G, silu)
+    if arena is not None:            # raw statistics in pre-zeroed scratch, finalized on the fly by every consumer
+        sums = arena.alloc(2 * B * G)
+        s.mean, s.rstd, s.raw_eps = sums[:B * G], sums[B * G:], float(eps)
+        ops.groupnorm_stats(x1, x2, s.mean, s.rstd, B, N, G, -1.0)
+    else:
+        s.mean = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+        s.rstd = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+        s.raw_eps = -1.0
+        ops.groupnorm_stats(x1, x2, s.mean, s.rstd, B, N, G, eps)
+    ops.groupnorm_apply(x1, x2, s.mean, s.rstd, gamma, beta, y, None, B, N, G, silu, raw_eps=s.raw_eps)
     return y, s
 
 
-def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres=None):
+def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres=None, arena=None):
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if x2 is not None else None
-    ws = torch.empty(B * G * 2, dtype=torch.float32, device=x1.device)
-    ops.groupnorm_bwd(dy, x1, x2, s.mean, s.rstd, gamma, beta, dres, dx1, dx2, ggamma, gbeta, ws, B, N, G, silu)
+    ws = arena.alloc(B * G * 2) if arena is not None else torch.empty(B * G * 2, dtype=torch.float32, device=x1.device)
+    ops.groupnorm_bwd(dy, x1, x2, s.mean, s.rstd, gamma, beta, dres, dx1, dx2, ggamma, gbeta, ws, B, N, G, silu,
+                      raw_eps=s.raw_eps, ws_zeroed=arena is not None)
     return dx1, dx2
 
 

@@ -131,18 +131,19 @@ def groupnorm_stats(x1, x2, mean, rstd, B, N, G, eps):
           "pt_groupnorm_stats")
 
 
-def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu):
+def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu, raw_eps=-1.0):
+    """raw_eps >= 0: mean/rstd hold the raw (sum, sum of squares) of groupnorm_stats(eps < 0)."""
     C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
     check(lib.pt_groupnorm_apply(_p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _p(xcat),
-                                 B, N, C1, C2, G, int(silu), pt_dtype(x1), _stream()), "pt_groupnorm_apply")
+                                 B, N, C1, C2, G, int(silu), raw_eps, pt_dtype(x1), _stream()), "pt_groupnorm_apply")
 
 
 def groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, G, silu,
-                  accumulate_dx2=False):
+                  accumulate_dx2=False, raw_eps=-1.0, ws_zeroed=False):
     C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
     check(lib.pt_groupnorm_bwd(_p(dy), _p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dres), _p(dx1),
                                _p(dx2), _p(dgamma), _p(dbeta), _p(ws), B, N, C1, C2, G, int(silu),
-                               int(accumulate_dx2), pt_dtype(x1), _stream()), "pt_groupnorm_bwd")
+                               int(accumulate_dx2), raw_eps, int(ws_zeroed), pt_dtype(x1), _stream()), "pt_groupnorm_bwd")
 
 
 def geglu_fwd(proj, out):

@@ -70,10 +70,10 @@ class ResnetBlock1D(nn.Module):
         """x = concat(x1, x2) (x2 None on the down path); tproj = this block's (B, Cout) f32 column slice of the batched
         time-embedding projection (row stride = tproj.stride(0))."""
         Cin, Cout = self.in_channels, self.out_channels
-        a1, s1 = E.groupnorm_fwd(x1, x2, st.f(self.norm1.weight), st.f(self.norm1.bias), B, N, self.groups, self.eps, True)
+        a1, s1 = E.groupnorm_fwd(x1, x2, st.f(self.norm1.weight), st.f(self.norm1.bias), B, N, self.groups, self.eps, True, arena=st.arena_active)
         h1, _ = E.conv3_fwd(a1, st.w(self.conv1.weight), st.f(self.conv1.bias), B, N, cin=Cin, cout=Cout, row_bias=tproj,
                             row_bias_ld=tproj.stride(0))
-        a2, s2 = E.groupnorm_fwd(h1, None, st.f(self.norm2.weight), st.f(self.norm2.bias), B, N, self.groups, self.eps, True)
+        a2, s2 = E.groupnorm_fwd(h1, None, st.f(self.norm2.weight), st.f(self.norm2.bias), B, N, self.groups, self.eps, True, arena=st.arena_active)
         if self.conv_shortcut is not None:
             M = B * N
             sc = torch.empty(M, Cout, dtype=x1.dtype, device=x1.device)
@@ -94,7 +94,7 @@ class ResnetBlock1D(nn.Module):
         da2 = E.conv3_bwd(dout, a2, st.w(self.conv2.weight), st.g(self.conv2.weight), st.g(self.conv2.bias), B, N, N,
                           cin=Cout, cout=Cout)
         dh1, _ = E.groupnorm_bwd(da2, h1, None, s2, st.f(self.norm2.weight), st.f(self.norm2.bias),
-                                 st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True)
+                                 st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True, arena=st.arena_active)
         # time-embedding projection: d tproj[b][c] = sum_n dh1[(b,n)][c]  (its GEMMs are batched over all blocks by the UNet)
         ops.colsum(dh1, dtproj, M, Cout, seg_rows=N, ld_out=dtproj.stride(0))
         da1 = E.conv3_bwd(dh1, a1, st.w(self.conv1.weight), st.g(self.conv1.weight), None, B, N, N, cin=Cin, cout=Cout)
@@ -109,4 +109,4 @@ class ResnetBlock1D(nn.Module):
         else:
             dres = dout
         return E.groupnorm_bwd(da1, x1, x2, s1, st.f(self.norm1.weight), st.f(self.norm1.bias),
-                               st.g(self.norm1.weight), st.g(self.norm1.bias), B, N, self.groups, True, dres=dres)
+                               st.g(self.norm1.weight), st.g(self.norm1.bias), B, N, self.groups, True, dres=dres, arena=st.arena_active)

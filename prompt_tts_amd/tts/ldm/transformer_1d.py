@@ -29,7 +29,7 @@ class Transformer1DModel(nn.Module):
         self.proj_out = nn.Conv1d(inner, in_channels, 1)
 
     def fwd(self, st, x, ctx, B, N, S):
-        hn, s = E.groupnorm_fwd(x, None, st.f(self.norm.weight), st.f(self.norm.bias), B, N, self.groups, 1e-6, False)
+        hn, s = E.groupnorm_fwd(x, None, st.f(self.norm.weight), st.f(self.norm.bias), B, N, self.groups, 1e-6, False, arena=st.arena_active)
         h0 = E.linear_fwd(hn, st.w(self.proj_in.weight), st.f(self.proj_in.bias))
         out, sv = self.transformer_blocks[0].fwd(st, h0, ctx, B, N, S, final_residual=x)
         return out, (x, hn, s, sv, B, N)
@@ -40,5 +40,5 @@ class Transformer1DModel(nn.Module):
         gw = st.g(self.proj_in.weight).view(self.inner, self.in_channels)
         dhn = E.linear_bwd(dh0, hn, st.w(self.proj_in.weight), gw, st.g(self.proj_in.bias))
         dx, _ = E.groupnorm_bwd(dhn, x, None, s, st.f(self.norm.weight), st.f(self.norm.bias), st.g(self.norm.weight),
-                                st.g(self.norm.bias), B, N, self.groups, False, dres=dout)
+                                st.g(self.norm.bias), B, N, self.groups, False, dres=dout, arena=st.arena_active)
         return dx, dctx

@@ -169,7 +169,7 @@ class Unet1DConditionModel(nn.Module):
             up.append((rec, sv_u))
         tape["up"] = up
         a, s = E.groupnorm_fwd(h, None, st.f(self.conv_norm_out.weight), st.f(self.conv_norm_out.bias), B, N,
-                               cfg["groups"], cfg["eps"], True)
+                               cfg["groups"], cfg["eps"], True, arena=st.arena_active)
         pred = torch.zeros(B * T, self.cpad, dtype=xt.dtype, device=dev)
         E.conv3_fwd(a, st.w(self.conv_out.weight), st.f(self.conv_out.bias), B, T, cin=C0, cout=cfg["out_channels"],
                     out=pred, ldc=self.cpad)
@@ -193,7 +193,7 @@ class Unet1DConditionModel(nn.Module):
         da = E.conv3_bwd(dpred, a, st.w(self.conv_out.weight), st.g(self.conv_out.weight), st.g(self.conv_out.bias),
                          B, T, T, cin=C0, cout=self.cpad)
         dh, _ = E.groupnorm_bwd(da, h, None, s, st.f(self.conv_norm_out.weight), st.f(self.conv_norm_out.bias),
-                                st.g(self.conv_norm_out.weight), st.g(self.conv_norm_out.bias), B, T, cfg["groups"], True)
+                                st.g(self.conv_norm_out.weight), st.g(self.conv_norm_out.bias), B, T, cfg["groups"], True, arena=st.arena_active)
         notify(self.conv_out); notify(self.conv_norm_out)
         dctx = None
         dskips = []

@@ -239,11 +239,18 @@ class TTSSingleSpeaker(nn.Module):
         cpad = self.unet.cpad
         xt = torch.empty(B * T, cpad, dtype=st.dtype, device=st.device)
         ops.add_noise(x0, noise, t, self.alphas_cumprod(st.device), xt, n_q, T, cpad)
-        pred, tape = self._forward_tokens(st, xt, t, ids, mask, B, T, S)
-        loss = loss_out if loss_out is not None else torch.zeros(1, dtype=torch.float32, device=st.device)
-        dpred = torch.empty_like(pred)
-        ops.mse_loss(pred, noise, loss, dpred, grad_scale, B, n_q, T, cpad)
-        self._backward_tokens(st, tape, dpred)
+        if st.arena is None:
+            st.arena = E.ZeroArena(st.device)
+        st.arena.reset()                 # one memset for every GroupNorm statistic / workspace of this forward + backward
+        st.arena_active = st.arena
+        try:
+            pred, tape = self._forward_tokens(st, xt, t, ids, mask, B, T, S)
+            loss = loss_out if loss_out is not None else torch.zeros(1, dtype=torch.float32, device=st.device)
+            dpred = torch.empty_like(pred)
+            ops.mse_loss(pred, noise, loss, dpred, grad_scale, B, n_q, T, cpad)
+            self._backward_tokens(st, tape, dpred)
+        finally:
+            st.arena_active = None
         return loss
 
     def train_step(self, x0, noise, t, ids, mask, lr=1e-5, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,

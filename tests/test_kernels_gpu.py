@@ -290,6 +290,37 @@ def test_groupnorm(dev, dtype, B, N, C1, C2, G, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_raw_statistics(dev, dtype):
+    """Raw mode (sums in caller-zeroed scratch, finalized by the consumers) == finalized mode, bit for bit."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(12)
+    B, N, C1, C2, G = 2, 96, 128, 64, 32
+    C = C1 + C2
+    x1, _ = rnd((B * N, C1), dtype, dev, g); x2, _ = rnd((B * N, C2), dtype, dev, g)
+    dy, _ = rnd((B * N, C), dtype, dev, g)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(dev); beta = (0.3 * torch.randn(C, generator=g)).to(dev)
+    outs = []
+    for raw in (False, True):
+        if raw:
+            sums = torch.zeros(2 * B * G, device=dev); mean, rstd = sums[:B * G], sums[B * G:]
+            ops.groupnorm_stats(x1, x2, mean, rstd, B, N, G, -1.0)
+            ws = torch.zeros(B * G * 2, device=dev)
+        else:
+            mean = torch.empty(B * G, device=dev); rstd = torch.empty(B * G, device=dev)
+            ops.groupnorm_stats(x1, x2, mean, rstd, B, N, G, 1e-5)
+            ws = torch.empty(B * G * 2, device=dev)
+        y = torch.empty(B * N, C, dtype=dtype, device=dev)
+        ops.groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, None, B, N, G, True, raw_eps=1e-5 if raw else -1.0)
+        dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2)
+        dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        ops.groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, None, dx1, dx2, dg, db, ws, B, N, G, True,
+                          raw_eps=1e-5 if raw else -1.0, ws_zeroed=raw)
+        outs.append((y, dx1, dx2))
+    for a, b in zip(*outs):                                  # statistics are atomics-ordered: tolerance, not equality
+        assert relerr(a, b.float().cpu()) < 1e-5 * (1 if dtype == torch.float32 else 1000)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_elementwise(dev, dtype):
     ops, L = _ops()
     g = torch.Generator().manual_seed(11)
