@@ -31,7 +31,7 @@ enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -127,10 +127,25 @@ int pt_attn_bwd(const pt_attn_desc* d, int dtype, pt_stream stream);
 /* nn.LayerNorm(C, eps) over rows of x[M][C]  (diffusers BasicTransformerBlock.norm1/2/3). */
 int pt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int64_t M, int64_t C, float eps, int dtype, pt_stream stream);
+/* Replicated destinations (pt_layernorm_bwd, pt_groupnorm_bwd, pt_colsum): float atomics execute at the memory side and
+ * hundreds of workgroups adding into ONE short row run ~14x below the chip-wide atomic rate.  With n_rep > 1 workgroup b adds
+ * into ptr + (b % n_rep) * rep_stride instead of ptr (ptr = replica 0 inside a zeroed scratch arena) and
+ * pt_fold_replicas sums the replicas into the real gradients once per step.  n_rep = 1: add straight into ptr. */
+typedef struct pt_fold_seg {
+  int64_t rep_off;       /* float offset of replica 0 in the arena                               */
+  int64_t rep_stride;    /* floats between replicas                                              */
+  int64_t dst_off;       /* float offset in the destination buffer                               */
+  int32_t n;             /* elements                                                             */
+  int32_t pad;
+} pt_fold_seg;
+/* dst[dst_off + i] += sum_r arena[rep_off + r * rep_stride + i] for every segment (max_n = largest n). */
+int pt_fold_replicas(const float* arena, float* dst, const pt_fold_seg* segs_dev, int64_t n_segs, int n_rep,
+                     int64_t max_n, pt_stream stream);
+
 /* dx = LN'(dy) [+ dres];  dgamma/dbeta += (f32 atomics). */
 int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                      const void* dres, void* dx, float* dgamma, float* dbeta,
-                     int64_t M, int64_t C, int dtype, pt_stream stream);
+                     int64_t M, int64_t C, int n_rep, int64_t rep_stride, int dtype, pt_stream stream);
 
 /* nn.GroupNorm(G, C, eps) [+ SiLU] on token-major x = concat(x1[B][N][C1], x2[B][N][C2]) (x2 may be NULL)
  * (tts/ldm/resnet.py:238-240,267-273; transformer_1d.py:251; unet_1d_condition.py:731-733).
@@ -149,7 +164,7 @@ int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float
                      const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                      float* dgamma, float* dbeta, float* ws,
                      int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int accumulate_dx2,
-                     float raw_eps, int ws_zeroed, int dtype, pt_stream stream);
+                     float raw_eps, int ws_zeroed, int n_rep, int64_t rep_stride, int dtype, pt_stream stream);
 
 /* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F]. */
 int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream);
@@ -167,7 +182,7 @@ int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, int dtype, 
  * seg_rows = M gives the bias gradient; seg_rows = rows per batch item gives the time-embedding gradient.
  * N need not be a multiple of the 16-byte chunk as long as ld is (pad columns are read, never written). */
 int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out /* stride between segments in out; 0: N */,
-              int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream);
+              int64_t M, int64_t N, int64_t seg_rows, int n_rep, int64_t rep_stride, int dtype, pt_stream stream);
 
 /* word_embedding(ids) + positional table (tts/models.py:112-115): out[b][s][:] = W[ids[b][s]][:] + pos[s][:]. */
 int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out,

@@ -61,6 +61,10 @@ class pt_param_seg(C.Structure):
                 ("layout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("frozen", C.c_int32)]
 
 
+class pt_fold_seg(C.Structure):
+    _fields_ = [("rep_off", C.c_int64), ("rep_stride", C.c_int64), ("dst_off", C.c_int64), ("n", C.c_int32), ("pad", C.c_int32)]
+
+
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 # name -> argtypes (all return int status unless noted); mirrors include/prompt_tts_hip.h one to one.
@@ -69,18 +73,19 @@ SIGNATURES = {
     "pt_attn_fwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_attn_bwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
-    "pt_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
+    "pt_fold_replicas": [_vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "pt_groupnorm_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp],
     "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _i32, _vp],
     "pt_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                         _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _vp],
+                         _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i64, _i32, _vp],
     "pt_geglu_fwd": [_vp, _vp, _i64, _i64, _i32, _vp],
     "pt_geglu_bwd": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pt_silu_fwd": [_vp, _vp, _i64, _i32, _vp],
     "pt_silu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_add": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_pairsum_rows": [_vp, _vp, _i64, _i64, _i32, _vp],
-    "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _vp],
     "pt_embedding_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_embedding_bwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pt_timestep_embedding": [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp],
@@ -111,7 +116,7 @@ def _load():
     lib.pt_status_string.argtypes = [C.c_int]
     lib.pt_struct_size.restype = C.c_int
     lib.pt_struct_size.argtypes = [C.c_int]
-    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc)):
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():

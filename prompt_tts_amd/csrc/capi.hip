@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 5; }
+extern "C" int pt_abi_version(void) { return 6; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
@@ -23,6 +23,7 @@ extern "C" int pt_struct_size(int which) {
     case 3: return (int)sizeof(pt_param_seg);
     case 4: return (int)sizeof(pt_rowconv_desc);
     case 5: return (int)sizeof(pt_lstm2_desc);
+    case 6: return (int)sizeof(pt_fold_seg);
     default: return -1;
   }
 }

@@ -86,10 +86,13 @@ __global__ __launch_bounds__(NT) void pairsum_kernel(const T* __restrict__ x, T*
   }
 }
 
-// out[seg][n] += sum over the segment's rows of dy[m][n]: block = run of rows inside ONE segment, thread = fixed chunk
+// out[seg][n] += sum over the segment's rows of dy[m][n]: block = run of rows inside ONE segment, thread = fixed chunk.
+// Float atomics execute at the memory side and every block adding into ONE short row is ~14x below the chip-wide atomic
+// rate (measured: 12 of this kernel's 20 us at 32768 x 512): block b therefore adds into replica (b % n_rep) of the
+// destination, `rep_stride` floats apart, and pt_fold_replicas sums the replicas once per step.
 template <typename T>
 __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out, int64_t ld_out,
-                                                    int64_t seg_rows, int N, int rows_per_block) {
+                                                    int64_t seg_rows, int N, int rows_per_block, int n_rep, int64_t rep_stride) {
   constexpr int EPC = Vec16<T>::N;
   const int CC = (N + EPC - 1) / EPC;
   const int CW = CC < NT ? CC : NT, RP = NT / CW;
@@ -97,9 +100,8 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, in
   const int64_t seg = blockIdx.y;
   const int64_t s0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t s1 = s0 + rows_per_block < seg_rows ? s0 + rows_per_block : seg_rows;
-  extern __shared__ float sh[];
-  for (int i = threadIdx.x; i < CC * EPC; i += NT) sh[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float sh[];                 // [RP][CC * EPC] partial sums of the row-lanes
+  const int NP = CC * EPC;
   if (rr < RP) {
     for (int c = cw; c < CC; c += CW) {
       float acc[EPC];
@@ -112,11 +114,30 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ dy, in
         for (int e = 0; e < EPC; ++e) acc[e] += v.get(e);
       }
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) atomicAdd(&sh[c * EPC + e], acc[e]);
+      for (int e = 0; e < EPC; ++e) sh[rr * NP + c * EPC + e] = acc[e];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += NT) unsafeAtomicAdd(out + seg * ld_out + i, sh[i]);
+  float* dst = out + (int64_t)(blockIdx.x % n_rep) * rep_stride + seg * ld_out;
+  for (int i = threadIdx.x; i < N; i += NT) {
+    float a = 0.f;
+    for (int k = 0; k < RP; ++k) a += sh[k * NP + i];
+#ifndef PT_DIAG_NO_COLATOMICS
+    unsafeAtomicAdd(dst + i, a);
+#endif
+  }
+}
+
+// dst[seg.dst_off + i] += sum_r arena[seg.rep_off + r * seg.rep_stride + i]: one launch per step folds every replicated
+// small gradient (biases, norm scales / shifts) into the flat gradient buffer.
+__global__ __launch_bounds__(NT) void fold_replicas_kernel(const float* __restrict__ arena, float* __restrict__ dst,
+                                                           const pt_fold_seg* __restrict__ segs, int n_rep) {
+  const pt_fold_seg sg = segs[blockIdx.y];
+  for (int i = blockIdx.x * NT + threadIdx.x; i < sg.n; i += gridDim.x * NT) {
+    float a = 0.f;
+    for (int r = 0; r < n_rep; ++r) a += arena[sg.rep_off + (int64_t)r * sg.rep_stride + i];
+    dst[sg.dst_off + i] += a;
+  }
 }
 
 // ---- embedding ---------------------------------------------------------------------------------------
@@ -286,8 +307,20 @@ extern "C" int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, 
               hipLaunchKernelGGL((pairsum_kernel<bf16_t>), dim3(grid_for(rows * C / 8)), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
 }
 
-extern "C" int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out, int64_t M, int64_t N, int64_t seg_rows, int dtype, pt_stream stream) {
+extern "C" int pt_fold_replicas(const float* arena, float* dst, const pt_fold_seg* segs_dev, int64_t n_segs, int n_rep,
+                                int64_t max_n, pt_stream stream) {
+  if (!arena || !dst || !segs_dev || n_segs <= 0 || n_segs > 65535 || n_rep <= 0 || max_n <= 0) return PT_ERR_ARG;
+  const int64_t bx = (max_n + NT - 1) / NT;
+  dim3 grid((unsigned)(bx < 16 ? bx : 16), (unsigned)n_segs);
+  hipLaunchKernelGGL(fold_replicas_kernel, grid, dim3(NT), 0, (hipStream_t)stream, arena, dst, segs_dev, n_rep);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out, int64_t M, int64_t N, int64_t seg_rows,
+                         int n_rep, int64_t rep_stride, int dtype, pt_stream stream) {
   if (ld_out <= 0) ld_out = N;
+  if (n_rep < 1 || (n_rep > 1 && rep_stride <= 0)) return PT_ERR_ARG;
   if (M <= 0 || N <= 0 || N > 16384 || seg_rows <= 0 || M % seg_rows != 0 || M / seg_rows > 65535) return PT_ERR_SHAPE;
   const int es = dtype == PT_F32 ? 4 : 2, epc = 16 / es;
   if (!pt_aligned16(dy) || (ld * es) % 16 != 0) return PT_ERR_ALIGN;
@@ -295,10 +328,12 @@ extern "C" int pt_colsum(const void* dy, int64_t ld, float* out, int64_t ld_out,
   hipStream_t s = (hipStream_t)stream;
   const int rpb = 64;
   dim3 grid((unsigned)((seg_rows + rpb - 1) / rpb), (unsigned)(M / seg_rows));
-  const size_t dyn = sizeof(float) * (size_t)((N + epc - 1) / epc * epc);
+  const int cc = (int)((N + epc - 1) / epc), cw = cc < NT ? cc : NT, rp = NT / cw;
+  const size_t dyn = sizeof(float) * (size_t)rp * cc * epc;
+  if (dyn > 64 * 1024) return PT_ERR_SHAPE;
   PT_DISPATCH(dtype,
-              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(NT), dyn, s, (const float*)dy, ld, out, ld_out, seg_rows, (int)N, rpb),
-              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(NT), dyn, s, (const bf16_t*)dy, ld, out, ld_out, seg_rows, (int)N, rpb));
+              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(NT), dyn, s, (const float*)dy, ld, out, ld_out, seg_rows, (int)N, rpb, n_rep, rep_stride),
+              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(NT), dyn, s, (const bf16_t*)dy, ld, out, ld_out, seg_rows, (int)N, rpb, n_rep, rep_stride));
 }
 
 extern "C" int pt_embedding_fwd(const int32_t* ids, const void* W, const float* pos, void* out, int64_t BS, int64_t S,

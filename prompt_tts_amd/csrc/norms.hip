@@ -58,13 +58,16 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, con
   }
 }
 
+// One wave per row, RW rows per wave in flight (their loads are issued together: with a single row per wave the kernel ran
+// at 2.4 TB/s, latency-bound).  dgamma / dbeta go to replica (block % n_rep) of the destination (see colsum_kernel).
 template <typename T, int MAXC>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
                                                     T* __restrict__ dx, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int64_t M, int C) {
+                                                    float* __restrict__ dbeta, int64_t M, int C, int n_rep, int64_t rep_stride) {
   constexpr int EPC = Vec16<T>::N;
+  constexpr int RW = MAXC == 1 ? 4 : (MAXC == 2 ? 2 : 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
   float gam[MAXC][EPC], dg[MAXC][EPC], db[MAXC][EPC];
@@ -74,39 +77,56 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { gam[j][e] = col < C ? gamma[col + e] : 0.f; dg[j][e] = 0.f; db[j][e] = 0.f; }
   }
-  for (int64_t row = (int64_t)blockIdx.x * (NT / 64) + wave; row < M; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    Vec16<T> vx[MAXC], vd[MAXC];
-    float c1 = 0.f, c2 = 0.f;
+  for (int64_t row0 = ((int64_t)blockIdx.x * (NT / 64) + wave) * RW; row0 < M; row0 += nwaves * RW) {
+    Vec16<T> vx[RW][MAXC], vd[RW][MAXC], vr[RW][MAXC];
+    float mu[RW], rs[RW];
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-      const int col = (lane + 64 * j) * EPC;
-      if (col < C) {
-        vx[j] = load16(x + row * C + col);
-        vd[j] = load16(dy + row * C + col);
+    for (int r = 0; r < RW; ++r) {
+      const int64_t row = row0 + r < M ? row0 + r : M - 1;       // clamped: the duplicate row is computed, never stored
+      mu[r] = mean[row]; rs[r] = rstd[row];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const float xh = (vx[j].get(e) - mu) * rs, d = vd[j].get(e), dxh = d * gam[j][e];
-          c1 += dxh; c2 += dxh * xh;
-          dg[j][e] += d * xh; db[j][e] += d;
+      for (int j = 0; j < MAXC; ++j) {
+        const int col = (lane + 64 * j) * EPC;
+        if (col < C) {
+          vx[r][j] = load16(x + row * C + col);
+          vd[r][j] = load16(dy + row * C + col);
+          if (dres) vr[r][j] = load16(dres + row * C + col);
         }
       }
     }
-    c1 = wave_sum(c1) / (float)C; c2 = wave_sum(c2) / (float)C;
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-      const int col = (lane + 64 * j) * EPC;
-      if (col < C) {
-        Vec16<T> o, r;
-        if (dres) r = load16(dres + row * C + col);
+    for (int r = 0; r < RW; ++r) {
+      const bool live = row0 + r < M;
+      float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const float xh = (vx[j].get(e) - mu) * rs;
-          float g = rs * (vd[j].get(e) * gam[j][e] - c1 - xh * c2);
-          if (dres) g += r.get(e);
-          o.set(e, g);
+      for (int j = 0; j < MAXC; ++j) {
+        const int col = (lane + 64 * j) * EPC;
+        if (col < C) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float xh = (vx[r][j].get(e) - mu[r]) * rs[r], d = vd[r][j].get(e), dxh = d * gam[j][e];
+            c1 += dxh; c2 += dxh * xh;
+            if (live) { dg[j][e] += d * xh; db[j][e] += d; }
+          }
         }
-        store16(dx + row * C + col, o);
+      }
+      c1 = wave_sum(c1) / (float)C; c2 = wave_sum(c2) / (float)C;
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+          const int col = (lane + 64 * j) * EPC;
+          if (col < C) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float xh = (vx[r][j].get(e) - mu[r]) * rs[r];
+              float g = rs[r] * (vd[r][j].get(e) * gam[j][e] - c1 - xh * c2);
+              if (dres) g += vr[r][j].get(e);
+              o.set(e, g);
+            }
+            store16(dx + (row0 + r) * C + col, o);
+          }
+        }
       }
     }
   }
@@ -125,9 +145,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
     }
     __syncthreads();
   }
+  const int64_t roff = (int64_t)(blockIdx.x % n_rep) * rep_stride;
   for (int c = threadIdx.x; c < C; c += NT) {
-    unsafeAtomicAdd(dgamma + c, sh[0][c]);
-    unsafeAtomicAdd(dbeta + c, sh[1][c]);
+#ifndef PT_DIAG_NO_COLATOMICS
+    unsafeAtomicAdd(dgamma + roff + c, sh[0][c]);
+    unsafeAtomicAdd(dbeta + roff + c, sh[1][c]);
+#endif
   }
 }
 
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ d
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ ws, GnGeom g,
-                                                         int silu) {
+                                                         int silu, int n_rep, int64_t rep_stride) {
   constexpr int EPC = Vec16<T>::N;
   const int b = blockIdx.y, r0 = blockIdx.x * g.rows_per_block, r1 = min(g.N, r0 + g.rows_per_block);
   const int cw = threadIdx.x % g.CW, rr = threadIdx.x / g.CW;
@@ -328,10 +351,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_sums_kernel(const T* __restrict__ d
     }
   }
   __syncthreads();
+  const int64_t roff = (int64_t)((blockIdx.x + gridDim.x * blockIdx.y) % n_rep) * rep_stride;
   for (int col = threadIdx.x; col < g.C; col += NT) {
     const float a = colg[col], bb = colb[col], gm = gamma[col];
-    unsafeAtomicAdd(dgamma + col, a);
-    unsafeAtomicAdd(dbeta + col, bb);
+#ifndef PT_DIAG_NO_COLATOMICS
+    unsafeAtomicAdd(dgamma + roff + col, a);
+    unsafeAtomicAdd(dbeta + roff + col, bb);
+#endif
     atomicAdd(&grp2[2 * (col / g.cpg)], gm * bb);        // A  = sum gamma*dz
     atomicAdd(&grp2[2 * (col / g.cpg) + 1], gm * a);     // Bq = sum gamma*dz*xhat
   }
@@ -432,12 +458,13 @@ int ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float*
 
 template <typename T>
 int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
-           void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, hipStream_t s) {
+           void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int n_rep, int64_t rep_stride, hipStream_t s) {
   constexpr int EPC = Vec16<T>::N;
   const int chunks = (int)((C / EPC + 63) / 64);
-  const int64_t want = (M + 3) / 4;
+  const int rw = chunks <= 1 ? 4 : (chunks <= 2 ? 2 : 1);
+  const int64_t want = (M + 4 * rw - 1) / (4 * rw);
   dim3 grid((unsigned)(want < 1024 ? want : 1024));       // 8 rows per wave at M = 32768: amortises the dgamma/dbeta atomics
-#define LN_B(MC) hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, M, (int)C)
+#define LN_B(MC) hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, M, (int)C, n_rep, rep_stride)
   if (chunks <= 1) LN_B(1); else if (chunks <= 2) LN_B(2); else if (chunks <= 4) LN_B(4); else return PT_ERR_SHAPE;
 #undef LN_B
   PT_LAUNCH_CHECK();
@@ -457,13 +484,14 @@ extern "C" int pt_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 extern "C" int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int dtype,
-                                pt_stream stream) {
+                                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int n_rep,
+                                int64_t rep_stride, int dtype, pt_stream stream) {
   if (M <= 0 || C <= 0 || C % 8 != 0) return PT_ERR_SHAPE;
+  if (n_rep < 1 || (n_rep > 1 && rep_stride <= 0)) return PT_ERR_ARG;
   if (!pt_aligned16(x) || !pt_aligned16(dy) || !pt_aligned16(dx) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32) return ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, s);
-  if (dtype == PT_BF16) return ln_bwd<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, s);
+  if (dtype == PT_F32) return ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, n_rep, rep_stride, s);
+  if (dtype == PT_BF16) return ln_bwd<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, n_rep, rep_stride, s);
   return PT_ERR_DTYPE;
 }
 
@@ -524,14 +552,14 @@ template <typename T>
 static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2, float* dgamma,
                     float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu,
-                    int acc_dx2, float raw_eps, int ws_zeroed, hipStream_t s) {
+                    int acc_dx2, float raw_eps, int ws_zeroed, int n_rep, int64_t rep_stride, hipStream_t s) {
   GnGeom g; int st = gn_geom<T>(g, N, C1, C2, G); if (st) return st;
   if (raw_eps >= 0.f) { g.raw_cnt = (float)N * (float)g.cpg; g.eps = raw_eps; }
   if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(float) * B * G * 2, s) != hipSuccess) return PT_ERR_LAUNCH;
   dim3 grid((unsigned)((N + g.rows_per_block - 1) / g.rows_per_block), (unsigned)B);
   const size_t dyn = sizeof(float) * (2 * (size_t)g.C + 2 * (size_t)g.G);
   hipLaunchKernelGGL((gn_bwd_sums_kernel<T>), grid, dim3(NT), dyn, s, (const T*)dy, (const T*)x1, (const T*)x2, mean,
-                     rstd, gamma, beta, dgamma, dbeta, ws, g, silu);
+                     rstd, gamma, beta, dgamma, dbeta, ws, g, silu, n_rep, rep_stride);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x1, (const T*)x2, mean,
                      rstd, gamma, beta, ws, (const T*)dres, (T*)dx1, (T*)dx2, g, silu, acc_dx2);
   PT_LAUNCH_CHECK();
@@ -541,13 +569,13 @@ static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float*
 extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                                 float* dgamma, float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2,
-                                int64_t G, int silu, int accumulate_dx2, float raw_eps, int ws_zeroed, int dtype,
-                                pt_stream stream) {
+                                int64_t G, int silu, int accumulate_dx2, float raw_eps, int ws_zeroed, int n_rep,
+                                int64_t rep_stride, int dtype, pt_stream stream) {
   if (B <= 0 || (C2 > 0 && (!x2 || !dx2))) return PT_ERR_SHAPE;
   if (!pt_aligned16(dy) || !pt_aligned16(x1) || !pt_aligned16(dx1) || (x2 && !pt_aligned16(x2)) ||
       (dx2 && !pt_aligned16(dx2)) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, s);
-  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, s);
+  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
+  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
   return PT_ERR_DTYPE;
 }

@@ -255,7 +255,8 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
         if gbias is not None:
             for c0 in range(0, N, 8192):                 # the column-sum kernel keeps its columns in LDS
                 c1 = min(N, c0 + 8192)
-                ops.colsum(dy[:, c0:c1], gbias[c0:c1], M, c1 - c0)
+                (gb,), n_rep, rstride = _rep(gbias[c0:c1])
+                ops.colsum(dy[:, c0:c1], gb, M, c1 - c0, n_rep=n_rep, rep_stride=rstride)
     on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
@@ -309,7 +310,8 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
                  gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
                  conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0)
         if gbias is not None:
-            ops.colsum(dy, gbias, Mred, gbias.numel())
+            (gb,), n_rep, rstride = _rep(gbias)
+            ops.colsum(dy, gb, Mred, gbias.numel(), n_rep=n_rep, rep_stride=rstride)
     on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
@@ -332,16 +334,25 @@ class GNState:
     __slots__ = ("mean", "rstd", "raw_eps")
 
 
+N_REP = int(__import__("os").environ.get("PT_GRAD_REPLICAS", "16"))
+
+
 class ZeroArena:
     """f32 scratch that is zero when handed out: ONE memset per training step (reset()) replaces a memset per GroupNorm
-    statistics / workspace buffer (3 launches per GroupNorm forward+backward, ~180 per step)."""
+    statistics / workspace buffer (3 launches per GroupNorm forward+backward, ~180 per step).  It also holds the REPLICATED
+    destinations of the small gradients that many workgroups accumulate with float atomics (biases, norm scales / shifts):
+    N_REP zeroed copies each, summed into the flat gradient buffer by one pt_fold_replicas launch (fold())."""
 
-    def __init__(self, device, n_floats=1 << 20):
+    def __init__(self, device, n_floats=6 << 20):
         self.buf = torch.zeros(n_floats, dtype=torch.float32, device=device)
         self.off = 0
         self.dirty = False
+        self.folds = []                  # (rep_off, rep_stride, dst data_ptr, n) not yet folded
+        self._seg_key = None; self._seg_dev = None
 
     def reset(self):
+        if self.folds:
+            raise RuntimeError("ZeroArena.reset() with unfolded gradient replicas")
         if self.dirty:
             self.buf[:self.off].zero_()
         self.off = 0
@@ -355,6 +366,56 @@ class ZeroArena:
         self.off += n_al
         self.dirty = True
         return out
+
+    def replicated(self, *dsts):
+        """Replica-0 views standing in for the 1-D f32 gradient views `dsts` (all the same length): (views, n_rep, stride)."""
+        n = dsts[0].numel()
+        n_al = (n + 63) // 64 * 64
+        if N_REP <= 1 or self.off + len(dsts) * N_REP * n_al > self.buf.numel():
+            return dsts, 1, 0
+        out = []
+        for d in dsts:
+            self.folds.append((self.off, n_al, d.data_ptr(), n))
+            out.append(self.buf[self.off:self.off + n])
+            self.off += N_REP * n_al
+        self.dirty = True
+        return out, N_REP, n_al
+
+    def fold(self, flat_g):
+        """Sum every pending replica set into flat_g (the destinations are views of it)."""
+        if not self.folds:
+            return
+        base = flat_g.data_ptr()
+        key = tuple((ro, rs, (dp - base) // 4, n) for ro, rs, dp, n in self.folds)
+        if key != self._seg_key:
+            raw = (L.pt_fold_seg * len(key))()
+            for i, (ro, rs, do, n) in enumerate(key):
+                if do < 0 or do + n > flat_g.numel():
+                    raise RuntimeError("replicated destination is not a view of the flat gradient buffer")
+                raw[i].rep_off, raw[i].rep_stride, raw[i].dst_off, raw[i].n = ro, rs, do, n
+            self._seg_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(flat_g.device)
+            self._seg_key = key
+        ops.fold_replicas(self.buf, flat_g, self._seg_dev, len(key), N_REP, max(k[3] for k in key))
+        self.folds.clear()
+
+
+_arena = [None]          # the arena of the fused forward+backward episode in progress (single-threaded host code)
+
+
+def set_arena(a):
+    _arena[0] = a
+
+
+def _rep(*dsts):
+    a = _arena[0]
+    if a is None:
+        return dsts, 1, 0
+    return a.replicated(*dsts)
+
+
+def fold_grad_replicas(flat_g):
+    if _arena[0] is not None:
+        _arena[0].fold(flat_g)
 
 
 def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu, arena=None):
@@ -378,8 +439,9 @@ def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = arena.alloc(B * G * 2) if arena is not None else torch.empty(B * G * 2, dtype=torch.float32, device=x1.device)
+    (ggamma, gbeta), n_rep, rstride = _rep(ggamma, gbeta)
     ops.groupnorm_bwd(dy, x1, x2, s.mean, s.rstd, gamma, beta, dres, dx1, dx2, ggamma, gbeta, ws, B, N, G, silu,
-                      raw_eps=s.raw_eps, ws_zeroed=arena is not None)
+                      raw_eps=s.raw_eps, ws_zeroed=arena is not None, n_rep=n_rep, rep_stride=rstride)
     return dx1, dx2
 
 
@@ -394,5 +456,6 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
 
 def layernorm_bwd(dy, x, stats, gamma, ggamma, gbeta, dres=None):
     dx = torch.empty_like(x)
-    ops.layernorm_bwd(dy, x, stats[0], stats[1], gamma, dres, dx, ggamma, gbeta)
+    (ggamma, gbeta), n_rep, rstride = _rep(ggamma, gbeta)
+    ops.layernorm_bwd(dy, x, stats[0], stats[1], gamma, dres, dx, ggamma, gbeta, n_rep=n_rep, rep_stride=rstride)
     return dx

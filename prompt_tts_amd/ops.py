@@ -119,10 +119,11 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
                                _stream()), "pt_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, n_rep=1, rep_stride=0):
+    """n_rep > 1: dgamma / dbeta are replica 0 of replicated destinations `rep_stride` floats apart (fold_replicas)."""
     M, Cc = x.shape
     check(lib.pt_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
-                               _p(dbeta), M, Cc, pt_dtype(x), _stream()), "pt_layernorm_bwd")
+                               _p(dbeta), M, Cc, n_rep, rep_stride, pt_dtype(x), _stream()), "pt_layernorm_bwd")
 
 
 def groupnorm_stats(x1, x2, mean, rstd, B, N, G, eps):
@@ -139,11 +140,12 @@ def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu, raw
 
 
 def groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, G, silu,
-                  accumulate_dx2=False, raw_eps=-1.0, ws_zeroed=False):
+                  accumulate_dx2=False, raw_eps=-1.0, ws_zeroed=False, n_rep=1, rep_stride=0):
     C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
     check(lib.pt_groupnorm_bwd(_p(dy), _p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dres), _p(dx1),
                                _p(dx2), _p(dgamma), _p(dbeta), _p(ws), B, N, C1, C2, G, int(silu),
-                               int(accumulate_dx2), raw_eps, int(ws_zeroed), pt_dtype(x1), _stream()), "pt_groupnorm_bwd")
+                               int(accumulate_dx2), raw_eps, int(ws_zeroed), n_rep, rep_stride, pt_dtype(x1), _stream()),
+          "pt_groupnorm_bwd")
 
 
 def geglu_fwd(proj, out):
@@ -173,11 +175,15 @@ def pairsum_rows(x, y):
     check(lib.pt_pairsum_rows(_p(x), _p(y), rows, Cc, pt_dtype(x), _stream()), "pt_pairsum_rows")
 
 
-def colsum(dy, out, M=None, N=None, seg_rows=None, ld_out=0):
+def colsum(dy, out, M=None, N=None, seg_rows=None, ld_out=0, n_rep=1, rep_stride=0):
     M = dy.shape[0] if M is None else M
     N = dy.shape[1] if N is None else N
-    check(lib.pt_colsum(_p(dy), dy.stride(0), _p(out), ld_out, M, N, M if seg_rows is None else seg_rows, pt_dtype(dy),
-                        _stream()), "pt_colsum")
+    check(lib.pt_colsum(_p(dy), dy.stride(0), _p(out), ld_out, M, N, M if seg_rows is None else seg_rows, n_rep, rep_stride,
+                        pt_dtype(dy), _stream()), "pt_colsum")
+
+
+def fold_replicas(arena, dst, segs_dev, n_segs, n_rep, max_n):
+    check(lib.pt_fold_replicas(_p(arena), _p(dst), _p(segs_dev), n_segs, n_rep, max_n, _stream()), "pt_fold_replicas")
 
 
 def embedding_fwd(ids, W, pos, out, S):

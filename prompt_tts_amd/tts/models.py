@@ -200,12 +200,14 @@ class TTSSingleSpeaker(nn.Module):
         if user_hook is not None:
             def hook(module):                     # weight gradients are produced on the side stream: join it first
                 E.join_side_stream(st.device)
+                E.fold_grad_replicas(st.flat_g)
                 user_hook(module)
         dctx = self.unet.bwd(st, utape, dpred, hook)
         self.text_encoder.bwd(st, sv_text, dctx)
         if hook is not None:
             hook(self.text_encoder)
         E.join_side_stream(st.device)
+        E.fold_grad_replicas(st.flat_g)
 
     def _forward_impl(self, sample, t, ids, mask):
         st = self.store
@@ -243,6 +245,7 @@ class TTSSingleSpeaker(nn.Module):
             st.arena = E.ZeroArena(st.device)
         st.arena.reset()                 # one memset for every GroupNorm statistic / workspace of this forward + backward
         st.arena_active = st.arena
+        E.set_arena(st.arena)
         try:
             pred, tape = self._forward_tokens(st, xt, t, ids, mask, B, T, S)
             loss = loss_out if loss_out is not None else torch.zeros(1, dtype=torch.float32, device=st.device)
@@ -251,6 +254,7 @@ class TTSSingleSpeaker(nn.Module):
             self._backward_tokens(st, tape, dpred)
         finally:
             st.arena_active = None
+            E.set_arena(None)
         return loss
 
     def train_step(self, x0, noise, t, ids, mask, lr=1e-5, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,

@@ -28,8 +28,9 @@ def timeit(fn, iters=20):
 def main():
     B, G = 32, 32
     print(f"{'kernel':22s} {'tokens':>7s} {'C':>5s} {'us':>8s} {'GB/s':>8s}")
-    for n in (1024, 512, 256, 128, 64):
-        for Cc in (512, 1024):
+    levels = (1024, 512, 256, 128, 64) if len(sys.argv) < 2 else tuple(int(a) for a in sys.argv[1].split(","))
+    for n in levels:
+        for Cc in (512, 1024) if len(sys.argv) < 3 else (int(sys.argv[2]),):
             M = B * n
             x = torch.randn(M, Cc, device=dev, dtype=bf); dy = torch.randn(M, Cc, device=dev, dtype=bf)
             gamma = torch.ones(Cc, device=dev); beta = torch.zeros(Cc, device=dev)
