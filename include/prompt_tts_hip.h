@@ -155,6 +155,11 @@ int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const flo
  * and finalize on the fly (raw_eps < 0: the arrays hold finalized statistics). */
 int pt_groupnorm_stats(const void* x1, const void* x2, float* mean, float* rstd,
                        int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, float eps, int dtype, pt_stream stream);
+/* statistics + normalisation in one call (writes finalized mean / rstd for the backward); bf16 inputs of up to 1024
+ * tokens per item run as ONE kernel that keeps a 64-channel slab of the item in registers. */
+int pt_groupnorm_fwd(const void* x1, const void* x2, const float* gamma, const float* beta, void* y, float* mean,
+                     float* rstd, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, float eps, int silu,
+                     int dtype, pt_stream stream);
 int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, void* y, void* xcat /* raw concat copy or NULL */,
                        int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, float raw_eps, int dtype,

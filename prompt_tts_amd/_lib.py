@@ -76,6 +76,7 @@ SIGNATURES = {
     "pt_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "pt_fold_replicas": [_vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "pt_groupnorm_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp],
+    "pt_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp],
     "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _i32, _vp],
     "pt_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i64, _i32, _vp],

@@ -3,6 +3,7 @@
 // so per-channel quantities (gamma/beta, scale/shift, dgamma/dbeta partials) live in registers.
 //   algorithmic bytes: LN fwd 2*M*C*s; LN bwd 3*M*C*s (+dres); GN stats M*C*s; GN apply 2*M*C*s;
 //   GN bwd 2*M*C*s (sums) + 3*M*C*s (apply)            (s = sizeof(T))
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -428,6 +429,187 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm "slab" kernels (bf16, N <= 1024 tokens per item): ONE launch per direction.  A workgroup of 64 CCH threads owns a
+// slab of 8 CCH channels (whole groups; CCH = 4: 32 channels, 256 threads) of one batch item and keeps it in REGISTERS (x:
+// 16 B chunks, NCH per thread; backward: x and dy), so statistics / group sums and the normalisation are one pass: each
+// activation byte is read once (the two-pass kernels read x twice forward, x and dy twice backward) and all of a thread's
+// loads are in flight together.  The grid is (C / 8 CCH) x B workgroups at EVERY UNet level, where the row-block grids of
+// the two-pass kernels shrink with N.  Thread t holds column chunk t % CCH of rows t / CCH + 64 i.
+// 32-channel slabs read half cache lines: the slab index is decoded XCD-aware so that the two slabs of a line run on the
+// same XCD (second toucher hits L2).  (A 512-thread / 64-channel version measured 3x slower INSIDE the training step than
+// alone: a 200-register 8-wave workgroup has to wait for a whole CU while the wgrad GEMMs hold half of each.)
+// ---------------------------------------------------------------------------------------------------
+struct GnSlab {
+  const bf16_t* x1; const bf16_t* x2; int C1, C2, C, N, G, cpg;
+  const float* gamma; const float* beta; float* mean; float* rstd; float eps; int silu;
+  bf16_t* y;                                                       // forward
+  const bf16_t* dy; const bf16_t* dres; bf16_t* dx1; bf16_t* dx2;     // backward
+  float* dgamma; float* dbeta; int acc_dx2, n_rep; int64_t rep_stride; float raw_cnt;
+};
+
+// sum over the lanes of this wave that hold the same column chunk (rows differ in the lane bits above log2(CCH))
+template <int CCH> __device__ __forceinline__ float rows_sum(float v) {
+  if (CCH <= 4) v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ int slab_index() {       // blocks b, b+8 share an XCD: give each XCD a run of adjacent slabs
+  const int n = gridDim.x, x = blockIdx.x;
+  return (n & 7) == 0 ? (x & 7) * (n >> 3) + (x >> 3) : x;
+}
+
+template <int NCH, int CCH>
+__global__ __launch_bounds__(64 * CCH) void gn_slab_fwd_kernel(const GnSlab p) {
+  using V = Vec16<bf16_t>;
+  constexpr int NW = CCH, RS = 64;                                // waves; row stride between a thread's chunks
+  __shared__ float red[NW][CCH][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cch = tid % CCH, r0 = tid / CCH;
+  const int b = blockIdx.y, col0 = slab_index() * 8 * CCH, col = col0 + 8 * cch;
+  const bool first = col0 < p.C1;
+  const bf16_t* src = first ? p.x1 + col : p.x2 + (col - p.C1);
+  const int64_t ld = first ? p.C1 : p.C2;
+  V vx[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int r = r0 + RS * i; r = r < p.N ? r : p.N - 1;
+    vx[i] = load16(src + ((int64_t)b * p.N + r) * ld);
+  }
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (r0 + RS * i < p.N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = vx[i].get(e); s += f; ss += f * f; }
+    }
+  s = rows_sum<CCH>(s); ss = rows_sum<CCH>(ss);
+  if (lane < CCH) { red[wave][cch][0] = s; red[wave][cch][1] = ss; }
+  __syncthreads();
+  const int cpgc = p.cpg >> 3, c_lo = cch / cpgc * cpgc;          // chunks of this thread's group inside the slab
+  float S = 0.f, SS = 0.f;
+  for (int w = 0; w < NW; ++w)
+    for (int c = c_lo; c < c_lo + cpgc; ++c) { S += red[w][c][0]; SS += red[w][c][1]; }
+  const float cnt = (float)p.N * (float)p.cpg;
+  const float mu = S / cnt, rs = rsqrtf(fmaxf(SS / cnt - mu * mu, 0.f) + p.eps);
+  if (r0 == 0 && cch == c_lo) { p.mean[b * p.G + col / p.cpg] = mu; p.rstd[b * p.G + col / p.cpg] = rs; }
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = rs * p.gamma[col + e]; sf[e] = p.beta[col + e] - mu * sc[e]; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int r = r0 + RS * i;
+    if (r < p.N) {
+      V o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float z = vx[i].get(e) * sc[e] + sf[e]; o.set(e, p.silu ? silu_f(z) : z); }
+      store16(p.y + ((int64_t)b * p.N + r) * p.C + col, o);
+    }
+  }
+}
+
+template <int NCH, int CCH>
+__global__ __launch_bounds__(64 * CCH) void gn_slab_bwd_kernel(const GnSlab p) {
+  using V = Vec16<bf16_t>;
+  constexpr int NW = CCH, RS = 64, SC = 8 * CCH;                  // waves; row stride; slab channels
+  __shared__ float red[NW][SC][2];           // per-wave column sums (dz*xhat, dz)
+  __shared__ float tot[2][SC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cch = tid % CCH, r0 = tid / CCH;
+  const int b = blockIdx.y, col0 = slab_index() * SC, col = col0 + 8 * cch;
+  const bool first = col0 < p.C1;
+  const bf16_t* src = first ? p.x1 + col : p.x2 + (col - p.C1);
+  const int64_t ld = first ? p.C1 : p.C2;
+  V vx[NCH], vd[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int r = r0 + RS * i; r = r < p.N ? r : p.N - 1;
+    const int64_t row = (int64_t)b * p.N + r;
+    vx[i] = load16(src + row * ld);
+    vd[i] = load16(p.dy + row * p.C + col);
+  }
+  float mu = p.mean[b * p.G + col / p.cpg], rs = p.rstd[b * p.G + col / p.cpg];
+  const float cnt = (float)p.N * (float)p.cpg;
+  if (p.raw_cnt > 0.f) { mu = mu / cnt; rs = rsqrtf(fmaxf(rs / cnt - mu * mu, 0.f) + p.eps); }
+  float ga[8], be[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ga[e] = p.gamma[col + e]; be[e] = p.beta[col + e]; dg[e] = 0.f; db[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (r0 + RS * i < p.N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (vx[i].get(e) - mu) * rs;
+        float dz = vd[i].get(e);
+        if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
+        dg[e] += dz * xh; db[e] += dz;
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg[e] = rows_sum<CCH>(dg[e]); db[e] = rows_sum<CCH>(db[e]); }
+  if (lane < CCH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[wave][8 * cch + e][0] = dg[e]; red[wave][8 * cch + e][1] = db[e]; }
+  }
+  __syncthreads();
+  if (tid < 2 * SC) {
+    const int c = tid % SC, k = tid / SC;
+    float a = 0.f;
+    for (int w = 0; w < NW; ++w) a += red[w][c][k];
+    tot[k][c] = a;
+    float* dst = (k == 0 ? p.dgamma : p.dbeta) + (int64_t)((blockIdx.x + gridDim.x * blockIdx.y) % p.n_rep) * p.rep_stride;
+    unsafeAtomicAdd(dst + col0 + c, a);
+  }
+  __syncthreads();
+  const int g_lo = (8 * cch) / p.cpg * p.cpg;                      // first slab column of this thread's group
+  float A = 0.f, Bq = 0.f;
+  for (int c = g_lo; c < g_lo + p.cpg; ++c) { const float gm = p.gamma[col0 + c]; A += gm * tot[1][c]; Bq += gm * tot[0][c]; }
+  A /= cnt; Bq /= cnt;
+  bf16_t* dbase = first ? p.dx1 + col : p.dx2 + (col - p.C1);
+  const bool accum = p.acc_dx2 && !first;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int r = r0 + RS * i;
+    if (r < p.N) {
+      const int64_t row = (int64_t)b * p.N + r;
+      V vr, old, o;
+      if (p.dres) vr = load16(p.dres + row * p.C + col);
+      bf16_t* dst = dbase + row * ld;
+      if (accum) old = load16(dst);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (vx[i].get(e) - mu) * rs;
+        float dz = vd[i].get(e);
+        if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
+        float gr = rs * (dz * ga[e] - A - xh * Bq);
+        if (p.dres) gr += vr.get(e);
+        if (accum) gr += old.get(e);
+        o.set(e, gr);
+      }
+      store16(dst, o);
+    }
+  }
+}
+
+// slab width in 16-byte chunks (4: 32 channels / 256 threads, 8: 64 channels / 512 threads), or 0: use the two-pass kernels
+inline int gn_slab_cch(int64_t N, int64_t C1, int64_t C2, int64_t G) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("PT_GN_SLAB"); enabled = e ? atoi(e) : 1; }
+  const int64_t C = C1 + C2;
+  if (!enabled || G <= 0 || C % G != 0 || N < 1 || N > 1024) return 0;
+  const int64_t cpg = C / G;
+  if ((cpg == 8 || cpg == 16 || cpg == 32) && C1 % 32 == 0 && C2 % 32 == 0) return 4;
+  if (cpg == 64 && C1 % 64 == 0 && C2 % 64 == 0) return 8;
+  return 0;
+}
+#define GN_SLAB_LAUNCH(KERNEL, CCH, N, B, s, p)                                                              \
+  do {                                                                                                       \
+    dim3 grid((unsigned)((p).C / (8 * CCH)), (unsigned)(B)), blk(64 * CCH);                                  \
+    if ((N) <= 64) hipLaunchKernelGGL((KERNEL<1, CCH>), grid, blk, 0, s, p);                                 \
+    else if ((N) <= 128) hipLaunchKernelGGL((KERNEL<2, CCH>), grid, blk, 0, s, p);                           \
+    else if ((N) <= 256) hipLaunchKernelGGL((KERNEL<4, CCH>), grid, blk, 0, s, p);                           \
+    else if ((N) <= 512) hipLaunchKernelGGL((KERNEL<8, CCH>), grid, blk, 0, s, p);                           \
+    else hipLaunchKernelGGL((KERNEL<16, CCH>), grid, blk, 0, s, p);                                          \
+  } while (0)
+
 template <typename T> int gn_geom(GnGeom& g, int64_t N, int64_t C1, int64_t C2, int64_t G) {
   constexpr int EPC = Vec16<T>::N;
   const int64_t C = C1 + C2;
@@ -548,6 +730,33 @@ extern "C" int pt_groupnorm_apply(const void* x1, const void* x2, const float* m
   return PT_ERR_DTYPE;
 }
 
+/* statistics + normalisation [+ SiLU] in one call: the slab kernel when the shape allows it, else stats / finalize / apply */
+extern "C" int pt_groupnorm_fwd(const void* x1, const void* x2, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, float eps, int silu,
+                                int dtype, pt_stream stream) {
+  if (B <= 0 || (C2 > 0 && !x2) || eps < 0.f) return PT_ERR_SHAPE;
+  if (!pt_aligned16(x1) || (x2 && !pt_aligned16(x2)) || !pt_aligned16(y)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int cch = dtype == PT_BF16 && B <= 65535 ? gn_slab_cch(N, C1, C2, G) : 0;
+  if (cch) {
+    GnSlab p{};
+    p.x1 = (const bf16_t*)x1; p.x2 = (const bf16_t*)x2; p.C1 = (int)C1; p.C2 = (int)C2; p.C = (int)(C1 + C2); p.N = (int)N;
+    p.G = (int)G; p.cpg = p.C / p.G; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd; p.eps = eps; p.silu = silu;
+    p.y = (bf16_t*)y;
+    if (cch == 4) GN_SLAB_LAUNCH(gn_slab_fwd_kernel, 4, N, B, s, p); else GN_SLAB_LAUNCH(gn_slab_fwd_kernel, 8, N, B, s, p);
+    PT_LAUNCH_CHECK();
+    return PT_OK;
+  }
+  int st;
+  if (dtype == PT_F32) {
+    if ((st = gn_stats_t<float>(x1, x2, mean, rstd, B, N, C1, C2, G, eps, s))) return st;
+    return gn_apply_t<float>(x1, x2, mean, rstd, gamma, beta, y, nullptr, B, N, C1, C2, G, silu, -1.f, s);
+  }
+  if (dtype != PT_BF16) return PT_ERR_DTYPE;
+  if ((st = gn_stats_t<bf16_t>(x1, x2, mean, rstd, B, N, C1, C2, G, eps, s))) return st;
+  return gn_apply_t<bf16_t>(x1, x2, mean, rstd, gamma, beta, y, nullptr, B, N, C1, C2, G, silu, -1.f, s);
+}
+
 template <typename T>
 static int gn_bwd_t(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2, float* dgamma,
@@ -575,6 +784,19 @@ extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, 
   if (!pt_aligned16(dy) || !pt_aligned16(x1) || !pt_aligned16(dx1) || (x2 && !pt_aligned16(x2)) ||
       (dx2 && !pt_aligned16(dx2)) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (n_rep < 1 || (n_rep > 1 && rep_stride <= 0)) return PT_ERR_ARG;
+  const int cch = dtype == PT_BF16 && B <= 65535 ? gn_slab_cch(N, C1, C2, G) : 0;
+  if (cch) {
+    GnSlab p{};
+    p.x1 = (const bf16_t*)x1; p.x2 = (const bf16_t*)x2; p.C1 = (int)C1; p.C2 = (int)C2; p.C = (int)(C1 + C2); p.N = (int)N;
+    p.G = (int)G; p.cpg = p.C / p.G; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+    p.eps = raw_eps; p.raw_cnt = raw_eps >= 0.f ? 1.f : 0.f; p.silu = silu;
+    p.dy = (const bf16_t*)dy; p.dres = (const bf16_t*)dres; p.dx1 = (bf16_t*)dx1; p.dx2 = (bf16_t*)dx2;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.acc_dx2 = accumulate_dx2; p.n_rep = n_rep; p.rep_stride = rep_stride;
+    if (cch == 4) GN_SLAB_LAUNCH(gn_slab_bwd_kernel, 4, N, B, s, p); else GN_SLAB_LAUNCH(gn_slab_bwd_kernel, 8, N, B, s, p);
+    PT_LAUNCH_CHECK();
+    return PT_OK;
+  }
   if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
   if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
   return PT_ERR_DTYPE;

@@ -195,6 +195,23 @@ def _side_stream(device):
     return st
 
 
+# The forward / dgrad chain is the critical path and the weight-gradient stream only fills what it leaves idle: the chain
+# therefore runs on a HIGH-priority stream (this device offers priorities 0 and -1), so that its workgroups are dispatched
+# ahead of queued wgrad workgroups instead of competing with them for every freed CU.
+MAIN_HIGH_PRIORITY = __import__("os").environ.get("PT_MAIN_PRIORITY", "1") != "0"
+_main = {}
+
+
+def main_stream(device):
+    """High-priority stream for the critical chain of a training step (None: stay on the caller's stream)."""
+    if not MAIN_HIGH_PRIORITY:
+        return None
+    st = _main.get(device)
+    if st is None:
+        st = _main[device] = torch.cuda.Stream(device=device, priority=-1)
+    return st
+
+
 def on_side_stream(fn, *tensors):
     """Run fn() (kernel launches reading `tensors`) on the wgrad side stream, ordered after the current stream."""
     if _DIAG_SKIP_WGRAD:                 # timing diagnostic only (wrong gradients): the main-stream chain by itself
@@ -422,6 +439,12 @@ def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu, arena=None):
     C = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     s = GNState()
     y = _empty(B * N, C, x1)
+    if x1.dtype == torch.bfloat16:   # one fused call (a single slab kernel for N <= 1024)
+        s.mean = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+        s.rstd = torch.empty(B * G, dtype=torch.float32, device=x1.device)
+        s.raw_eps = -1.0
+        ops.groupnorm_fwd(x1, x2, gamma, beta, y, s.mean, s.rstd, B, N, G, eps, silu)
+        return y, s
     if arena is not None:            # raw statistics in pre-zeroed scratch, finalized on the fly by every consumer
         sums = arena.alloc(2 * B * G)
         s.mean, s.rstd, s.raw_eps = sums[:B * G], sums[B * G:], float(eps)

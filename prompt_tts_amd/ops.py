@@ -132,6 +132,13 @@ def groupnorm_stats(x1, x2, mean, rstd, B, N, G, eps):
           "pt_groupnorm_stats")
 
 
+def groupnorm_fwd(x1, x2, gamma, beta, y, mean, rstd, B, N, G, eps, silu):
+    """Statistics + normalisation [+ SiLU] in one call; mean / rstd come back finalized."""
+    C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
+    check(lib.pt_groupnorm_fwd(_p(x1), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), B, N, C1, C2, G, eps,
+                               int(silu), pt_dtype(x1), _stream()), "pt_groupnorm_fwd")
+
+
 def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu, raw_eps=-1.0):
     """raw_eps >= 0: mean/rstd hold the raw (sum, sum of squares) of groupnorm_stats(eps < 0)."""
     C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0

@@ -259,7 +259,21 @@ class TTSSingleSpeaker(nn.Module):
 
     def train_step(self, x0, noise, t, ids, mask, lr=1e-5, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,
                    max_grad_norm=1.0, reducer=None):
-        """One optimizer step: zero grads, fused loss+backward, [DP all-reduce], clip, AdamW (train.py:79-120)."""
+        """One optimizer step: zero grads, fused loss+backward, [DP all-reduce], clip, AdamW (train.py:79-120).
+        Runs on a high-priority stream ordered after / before the caller's current stream (engine.main_stream)."""
+        st = self.store
+        hs = E.main_stream(st.device)
+        if hs is None:
+            return self._train_step(x0, noise, t, ids, mask, lr, betas, eps, weight_decay, max_grad_norm, reducer)
+        cur = torch.cuda.current_stream(st.device)
+        hs.wait_stream(cur)
+        with torch.cuda.stream(hs):
+            loss, gn = self._train_step(x0, noise, t, ids, mask, lr, betas, eps, weight_decay, max_grad_norm, reducer)
+        cur.wait_stream(hs)
+        loss.record_stream(cur); gn.record_stream(cur)
+        return loss, gn
+
+    def _train_step(self, x0, noise, t, ids, mask, lr, betas, eps, weight_decay, max_grad_norm, reducer):
         st = self.store
         st.zero_grad()
         if reducer is not None:

@@ -290,6 +290,43 @@ def test_groupnorm(dev, dtype, B, N, C1, C2, G, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,C1,C2,G,silu", [(2, 1024, 512, 0, 32, True), (2, 96, 256, 256, 32, True), (3, 700, 512, 512, 32, True),
+                                               (2, 70, 64, 0, 32, False), (1, 1030, 128, 0, 8, True), (2, 200, 512, 0, 8, True),
+                                               (2, 64, 96, 32, 16, False)])
+def test_groupnorm_fused_forward_backward(dev, dtype, B, N, C1, C2, G, silu):
+    """pt_groupnorm_fwd (one slab kernel for bf16, N <= 1024, whole 64-channel slabs) + pt_groupnorm_bwd against torch."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(13)
+    C = C1 + C2
+    x1, x1f = rnd((B * N, C1), dtype, dev, g)
+    x2, x2f = rnd((B * N, C2), dtype, dev, g) if C2 else (None, None)
+    dy, dyf = rnd((B * N, C), dtype, dev, g); dres, dresf = rnd((B * N, C), dtype, dev, g)
+    gamma = 1 + 0.3 * torch.randn(C, generator=g); beta = 0.3 * torch.randn(C, generator=g)
+    xcat = (torch.cat([x1f, x2f], 1) if C2 else x1f)
+    xr = xcat.view(B, N, C).permute(0, 2, 1).clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    z = F.group_norm(xr, G, gr, br, 1e-5); ref = F.silu(z) if silu else z
+    ref.backward(dyf.view(B, N, C).permute(0, 2, 1))
+    mean = torch.empty(B * G, device=dev); rstd = torch.empty(B * G, device=dev)
+    y = torch.empty(B * N, C, dtype=dtype, device=dev)
+    ops.groupnorm_fwd(x1, x2, gamma.to(dev), beta.to(dev), y, mean, rstd, B, N, G, 1e-5, silu)
+    assert relerr(y.view(B, N, C).permute(0, 2, 1), ref) < TOL[dtype]
+    xg = xcat.view(B, N, G, C // G).permute(0, 2, 1, 3).reshape(B * G, -1)
+    assert relerr(mean, xg.mean(1)) < 1e-4 + TOL[dtype] * 0 and relerr(rstd, (xg.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    dx1 = torch.empty_like(x1); dx2 = torch.ones_like(x2) if C2 else None
+    n_rep, C_al = 4, (C + 63) // 64 * 64
+    rep = torch.zeros(2, n_rep, C_al, device=dev); ws = torch.empty(B * G * 2, device=dev)
+    ops.groupnorm_bwd(dy, x1, x2, mean, rstd, gamma.to(dev), beta.to(dev), dres, dx1, dx2, rep[0, 0], rep[1, 0], ws, B, N, G,
+                      silu, accumulate_dx2=True, n_rep=n_rep, rep_stride=C_al)
+    dg = rep[0].sum(0)[:C]; db = rep[1].sum(0)[:C]
+    dxref = xr.grad.permute(0, 2, 1).reshape(B * N, C) + dresf
+    assert relerr(dx1, dxref[:, :C1]) < TOL[dtype] * 2
+    if C2:
+        assert relerr(dx2, dxref[:, C1:] + 1.0) < TOL[dtype] * 2
+    assert relerr(dg, gr.grad) < TOL[dtype] * 2 and relerr(db, br.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_groupnorm_raw_statistics(dev, dtype):
     """Raw mode (sums in caller-zeroed scratch, finalized by the consumers) == finalized mode, bit for bit."""
     ops, L = _ops()
