@@ -188,10 +188,16 @@ _side = {}
 _DIAG_SKIP_WGRAD = __import__("os").environ.get("PT_DIAG_SKIP_WGRAD", "0") == "1"
 
 
+N_SIDE = int(__import__("os").environ.get("PT_SIDE_STREAMS", "1"))     # wgrad launches rotate over this many side streams
+_side_rr = [0]
+
+
 def _side_stream(device):
-    st = _side.get(device)
+    _side_rr[0] = (_side_rr[0] + 1) % N_SIDE
+    key = (device, _side_rr[0])
+    st = _side.get(key)
     if st is None:
-        st = _side[device] = torch.cuda.Stream(device=device)
+        st = _side[key] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -229,9 +235,10 @@ def on_side_stream(fn, *tensors):
 
 
 def join_side_stream(device):
-    st = _side.get(device)
-    if st is not None:
-        torch.cuda.current_stream(device).wait_stream(st)
+    cur = torch.cuda.current_stream(device)
+    for (dev, _), st in _side.items():
+        if dev == device:
+            cur.wait_stream(st)
 
 
 def _empty(rows, cols, like):
