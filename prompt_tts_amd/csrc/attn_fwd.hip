@@ -94,12 +94,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       const float alpha = __builtin_amdgcn_exp2f((m[qt] - mn) * sl2);
       m[qt] = mn;
       float rs = 0.f;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t sl2v = {sl2, sl2}, mn2v = {mn * sl2, mn * sl2};
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f((s[kt][qt][r] - mn) * sl2);
-          s[kt][qt][r] = pv; rs += pv;
+        for (int r = 0; r < 4; r += 2) {          // s * sl2 - mn * sl2 as one packed FMA per pair (the loop is VALU-bound)
+          const f32x2_t sv = {s[kt][qt][r], s[kt][qt][r + 1]};
+          const f32x2_t tv = __builtin_elementwise_fma(sv, sl2v, -mn2v);
+          const float p0 = __builtin_amdgcn_exp2f(tv[0]), p1 = __builtin_amdgcn_exp2f(tv[1]);
+          s[kt][qt][r] = p0; s[kt][qt][r + 1] = p1; rs += p0 + p1;
         }
       l[qt] = l[qt] * alpha + rs;
 #pragma unroll
