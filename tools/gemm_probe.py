@@ -28,20 +28,26 @@ def build(ablate):
     return lib
 
 
+NBUF = int(os.environ.get("PT_PROBE_NBUF", "1"))      # > 1: rotate over that many operand / output sets (defeats the 256 MB L3)
+
+
 def run(lib, M, N, K, iters=30):
-    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
-    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    d = L.pt_gemm_desc(); d.M, d.N, d.K = M, N, K
-    d.A.p, d.A.ld = a.data_ptr(), K; d.B.p, d.B.ld = w.data_ptr(), K
-    d.C, d.ldc, d.split_k, d.alpha = c.data_ptr(), N, 1, 1.0
+    descs = []; keep = []
+    for _ in range(NBUF):
+        a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+        c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        d = L.pt_gemm_desc(); d.M, d.N, d.K = M, N, K
+        d.A.p, d.A.ld = a.data_ptr(), K; d.B.p, d.B.ld = w.data_ptr(), K
+        d.C, d.ldc, d.split_k, d.alpha = c.data_ptr(), N, 1, 1.0
+        descs.append(d); keep.append((a, w, c))
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for _ in range(3):
-        assert lib.pt_gemm(C.byref(d), 1, st) == 0
+    for i in range(3):
+        assert lib.pt_gemm(C.byref(descs[i % NBUF]), 1, st) == 0
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        lib.pt_gemm(C.byref(d), 1, st)
+    for i in range(iters):
+        lib.pt_gemm(C.byref(descs[i % NBUF]), 1, st)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
