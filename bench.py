@@ -239,15 +239,31 @@ def main():
         # dominant symbol's average is what profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats) must agree with
         kern = ops.profile_one_step(step)
         mf = {k: v for k, v in kern.items() if "tflops" in v and k.startswith("gemm<" + args.dtype)}
+        # HBM-side bytes come from the committed rocprofv3 PMC passes of this same command (profiles/, see tools/rocprof_summary.py)
+        pmc = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if args.workload == "B" and args.dtype == "bf16" and not args.batch and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            out["roofline"]["traffic"] = pmc["step_bytes"]
+            out["roofline"]["traffic_note"] = "HBM-side bytes of one step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_traffic.json)"
         if mf:
             name = max(mf, key=lambda k: mf[k]["ms_total"])
-            tpl = {"NN": "false, false", "NT": "false, true", "TT": "true, true"}[name.split(",")[1]]   # <TA, TB> of the label
+            ta, tb = name.split(",")[1]
+            tpl = f"{'true' if ta == 'T' else 'false'}, {'true' if tb == 'T' else 'false'}, {'true' if 'atomic' in name else 'false'}"
+            el = "bf16_t" if args.dtype == "bf16" else "float"
+            symbol = f"gemm_kernel<{el}, {tpl}, 0, {1 if name.endswith('/conv') else 0}, 128, 128>"
+            traffic = None
+            if pmc is not None and "atomic" in name:            # the wgrads run on the two-stage kernel only: one symbol
+                hit = [k for k in pmc["kernels"] if symbol in k["kernel"]]
+                traffic = hit[0]["bytes_per_launch"] if hit else None
             out["roofline_kernel"] = {
-                "kernel": name, "symbol": f"gemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'}, {tpl}, "
-                                          f"{'true' if 'atomic' in name else 'false'}, ..., 128>",
+                "kernel": name, "symbol": symbol if "atomic" in name else symbol + " / gemm8p_kernel<...> (tile chosen per shape)",
                 "bound": "mfma", "calls_per_step": mf[name]["calls"], "avg_us": mf[name]["ms_avg"] * 1e3,
                 "algorithmic_gflop_per_launch": mf[name]["gflop_avg"], "achieved": mf[name]["tflops"], "peak": peak,
-                "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "share_of_step": mf[name]["ms_total"] / (step_s * 1e3)}
+                "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "traffic": traffic,
+                "share_of_step": mf[name]["ms_total"] / (step_s * 1e3),
+                "note": "averaged over all launches of one step, measured while the dgrad chain runs beside it on the main stream"}
         if args.kernel_timing:
             out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_decode:

@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 result databases (rocpd sqlite) into the small text files committed under profiles/.
+
+  rocprof_summary.py stats  <results.db> <out.csv>      per-kernel Calls / total / average / min / max (like --stats csv)
+  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>
+        per-kernel and per-step HBM-side bytes from FETCH_SIZE / WRITE_SIZE (separate passes).  Units and the gfx950
+        correction follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB-like units of 1024 B as rocprofv3
+        reports them here (checked against the fused AdamW kernel, whose traffic is 16 B read + 14 B written per parameter);
+        FETCH_SIZE is DOUBLED (gfx950 tallies 128-B requests at 64 B).
+"""
+import collections
+import json
+import re
+import sqlite3
+import subprocess
+import sys
+
+
+def _tables(db):
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    pick = lambda key: [t for t in tabs if key in t][0]
+    return pick("kernel_dispatch"), pick("kernel_symbol"), ([t for t in tabs if "pmc_event" in t] or [None])[0]
+
+
+def _demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(n[:-3] if n.endswith(".kd") else n for n in names),
+                             capture_output=True, text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
+
+
+def stats(path, out):
+    db = sqlite3.connect(path)
+    kd, ks, _ = _tables(db)
+    rows = db.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+                      f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    dm = _demangle([r[0] for r in rows])
+    with open(out, "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+        for n, c, t, a, mn, mx in rows:
+            f.write(f'"{dm[n]}",{c},{t},{a:.1f},{100.0 * t / total:.2f},{mn},{mx}\n')
+
+
+def _per_step(path):
+    db = sqlite3.connect(path)
+    kd, ks, pmc = _tables(db)
+    rows = db.execute(f"select d.start, s.kernel_name, d.dispatch_id, e.value from {pmc} e join {kd} d on e.event_id=d.event_id "
+                      f"join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
+    disp = collections.OrderedDict()
+    for st, n, did, v in rows:
+        disp[(st, did, n)] = disp.get((st, did, n), 0) + v
+    items = list(disp.items())
+    marks = [i for i, (k, _) in enumerate(items) if "adamw_kernel" in k[2]]
+    seg = items[marks[-2] + 1:marks[-1] + 1]          # one whole training step (optimizer kernel to optimizer kernel)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for (_, _, n), v in seg:
+        agg[n][0] += 1; agg[n][1] += v
+    return agg
+
+
+def pmc(fetch_db, write_db, out):
+    F, W = _per_step(fetch_db), _per_step(write_db)
+    names = sorted(set(F) | set(W), key=lambda n: -(2 * F.get(n, [0, 0])[1] + W.get(n, [0, 0])[1]))
+    dm = _demangle(names)
+    kern = []
+    for n in names:
+        calls = max(F.get(n, [0, 0])[0], W.get(n, [0, 0])[0])
+        rd = 2.0 * F.get(n, [0, 0])[1] * 1024.0; wr = W.get(n, [0, 0])[1] * 1024.0
+        kern.append({"kernel": re.sub(r"\(anonymous namespace\)::", "", dm[n])[:160], "calls_per_step": calls,
+                     "read_bytes_per_step": rd, "write_bytes_per_step": wr,
+                     "bytes_per_launch": (rd + wr) / max(calls, 1)})
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`; one training "
+                     "step; FETCH_SIZE doubled (gfx950), unit 1024 B", 
+           "step_read_bytes": sum(k["read_bytes_per_step"] for k in kern), "step_write_bytes": sum(k["write_bytes_per_step"] for k in kern),
+           "kernels": kern[:40]}
+    res["step_bytes"] = res["step_read_bytes"] + res["step_write_bytes"]
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        raise SystemExit(__doc__)
