@@ -109,6 +109,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
   const int g = lane >> 4, li = lane & 15;
   if (ATOMIC) {
     float* C = reinterpret_cast<float*>(p.C);
+    if (PT_GEMM_ABLATE == 3 || PT_GEMM_ABLATE == 4) {      // probe: keep the accumulators live, issue no atomics
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

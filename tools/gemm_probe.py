@@ -108,6 +108,20 @@ if __name__ == "__main__":
         name, M, N, K = SHAPES[int(sys.argv[2])]
         print(name, run(lib, M, N, K, iters=10), "us")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--bwd-ab":    # ablation variants on the wgrad shapes (split-K sized for 512 workgroups)
+        import math
+        variants = [int(x) for x in sys.argv[2:]] or [0, 1, 2, 3]
+        libs = {v: build(v) for v in variants}
+        print("wgrad shape".ljust(22) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
+        for name, T, NO, KI in BWD_SHAPES:
+            tiles = math.ceil(NO / 128) * math.ceil(KI / 128)
+            sk = max(1, min(512 // tiles, T // 64 // 4, 64))
+            row = f"{name} sk{sk}".ljust(22)
+            for v in variants:
+                us = run_mode(libs[v], "wgrad", T, NO, KI, sk)
+                row += f"{us:9.1f}/{2.0 * T * NO * KI / us / 1e6:6.0f}".rjust(18)
+            print(row, flush=True)
+        sys.exit(0)
     variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]
     libs = {v: build(v) for v in variants}
     print("shape".ljust(18) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
