@@ -53,7 +53,9 @@ enum pt_rowmap {    /* src(n, tap) for PT_V_CONV; "invalid" rows read as zero */
   PT_MAP_UP2 = 2,       /* (n + tap - 1) >> 1 over 2*n_in (nearest x2 upsample, then conv k3)          */
   PT_MAP_S2_DGRAD = 3,  /* u = n + tap - 1 ; u even ? u/2 : invalid   (dgrad of the stride-2 conv)     */
   PT_MAP_CAUSAL_REFLECT = 4, /* u = n + tap - (taps-1) ; u < 0 ? -u : u   (Encodec causal conv, reflect left pad) */
-  PT_MAP_BACK = 5       /* u = n - tap ; u < 0 invalid                (the two taps of a stride-r transposed conv) */
+  PT_MAP_BACK = 5,      /* u = n - tap ; u < 0 invalid                (the two taps of a stride-r transposed conv) */
+  PT_MAP_STRIDED_REFLECT = 6 /* u = n*stride + tap - (taps-stride) ; u < 0 ? -u : u  (Encodec ENCODER causal conv k = taps,
+                                stride r, reflect left pad k - r; n_in = stride * n_out)                              */
 };
 
 typedef struct pt_operand {
@@ -61,7 +63,7 @@ typedef struct pt_operand {
   const void* p2; int64_t ld2; int64_t c_split;     /* PT_V_CONCAT */
   int32_t kind;   int32_t trans;
   int32_t taps;   int32_t cin;  int32_t rowmap;     /* PT_V_CONV / PT_V_WFLIP (cin = cout there) */
-  int32_t _pad;
+  int32_t stride;                                   /* PT_MAP_STRIDED_REFLECT only */
   int64_t n_out;  int64_t n_in;                     /* rows per batch item of the output / source */
 } pt_operand;
 
@@ -261,9 +263,16 @@ typedef struct pt_rowconv_desc {
   const void* x2; int64_t ldx2; int32_t cin2; int32_t elu_x2;
   const void* w; int64_t ldw;      /* [N][ldw], ldw = K rounded up to 32, zero padded                       */
   const float* bias; int32_t N; int32_t act;   /* act: 0 none, 1 ELU                                        */
-  void* y; int64_t ldy; int32_t y_f32; int32_t _pad;
+  void* y; int64_t ldy; int32_t y_f32;
+  int32_t stride;                  /* PT_MAP_STRIDED_REFLECT: x has stride * n_rows rows per batch item               */
 } pt_rowconv_desc;
 int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream);
+
+/* One stage of the residual vector quantiser's ENCODE (data_preparation/generate_code.py:48 -> encodec quantizer.encode):
+ * scores [M][bins] f32 = 2 x.e_j - |e_j|^2 (computed by the caller with an f32 pt_gemm: alpha = 2, bias = -|e|^2);
+ * codes[b][q][t] = first argmax_j scores[(b,t)][j];  residual[(b,t)][:] -= codebook[argmax][:]   (all f32). */
+int pt_rvq_search(const float* scores, const float* codebook, float* residual, int64_t* codes,
+                  int64_t B, int64_t n_q, int64_t T, int64_t q, int64_t bins, int64_t dim, pt_stream stream);
 
 /* Two-layer LSTM(H) over T steps + skip + ELU (encodec SLSTM; gate order i,f,g,o as torch.nn.LSTM):
  *   xg0   [B*T][4H]  = x W_ih0^T + b_ih0 + b_hh0  (computed by the caller with pt_gemm)

@@ -1,4 +1,5 @@
-"""Oracle restatement of the Encodec 24 kHz DECODE path (decode_codec.py:8-16 -> encodec ^0.1.1).  TEST INFRA ONLY.
+"""Oracle restatement of the Encodec 24 kHz DECODE and ENCODE paths (decode_codec.py:8-16, data_preparation/
+generate_code.py:45-51 -> encodec ^0.1.1).  TEST INFRA ONLY.
 
 The `encodec` package is absent from /root/reference and from this image; pretrained weights are fetched by URL in
 the reference and are unavailable offline.  This follows the published architecture (SEANet decoder: causal,
@@ -78,6 +79,110 @@ def decode(codes, W):
         h = causal_conv1d(F.elu(h), W[f"res{i}.c1.w"], W[f"res{i}.c1.b"])
         x = causal_conv1d(x, W[f"res{i}.sc.w"], W[f"res{i}.sc.b"]) + h
     return causal_conv1d(F.elu(x), W["final.w"], W["final.b"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ENCODE path (data_preparation/generate_code.py:45-51 -> encodec ^0.1.1 `model.encode`): SEANet encoder (mirror of the
+# decoder: conv k7 1->32; four stages {residual block, ELU, causal strided conv k=2r stride r, C -> 2C} with r = 2,4,5,8;
+# 2-layer LSTM + skip; ELU; conv k7 512->128), then residual vector quantisation with the first n_q codebooks:
+# idx = argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2), residual -= e_idx.  Lengths that are multiples of 320 need no extra padding.
+# Encoder weights (effective): enc.conv0.{w,b} (32,1,7) | enc.res{i}.{c3,c1,sc}.{w,b} | enc.down{i}.{w,b} (2C,C,2r) |
+# enc.lstm.{w_ih,w_hh,b_ih,b_hh}{0,1} | enc.final.{w,b} (128,512,7)
+# ---------------------------------------------------------------------------------------------------------------------
+ENC_RATIOS = (2, 4, 5, 8)
+
+
+def causal_strided_conv1d(x, w, b, stride):
+    """Conv1d(k, stride) with reflect left padding of (k - stride); input length must be a multiple of the stride."""
+    pad = w.shape[2] - stride
+    if x.shape[-1] % stride != 0:
+        raise ValueError("length must be a multiple of the stride (no extra right padding is modelled)")
+    if pad > 0:
+        x = F.pad(x, (pad, 0), mode="reflect")
+    return F.conv1d(x, w, b, stride=stride)
+
+
+def encoder_embeddings(wav, W):
+    """wav (B, 1, L) f32, L % 320 == 0 -> embeddings (B, 128, L/320)."""
+    if wav.dim() != 3 or wav.shape[1] != 1 or wav.shape[-1] % 320 != 0:
+        raise ValueError("wav must be (B, 1, L) with L a multiple of 320")
+    x = causal_conv1d(wav, W["enc.conv0.w"], W["enc.conv0.b"])
+    for i, r in enumerate(ENC_RATIOS):
+        h = causal_conv1d(F.elu(x), W[f"enc.res{i}.c3.w"], W[f"enc.res{i}.c3.b"])
+        h = causal_conv1d(F.elu(h), W[f"enc.res{i}.c1.w"], W[f"enc.res{i}.c1.b"])
+        x = causal_conv1d(x, W[f"enc.res{i}.sc.w"], W[f"enc.res{i}.sc.b"]) + h
+        x = causal_strided_conv1d(F.elu(x), W[f"enc.down{i}.w"], W[f"enc.down{i}.b"], r)
+    x = lstm2_skip(x, {k[4:]: v for k, v in W.items() if k.startswith("enc.lstm.")})
+    return causal_conv1d(F.elu(x), W["enc.final.w"], W["enc.final.b"])
+
+
+def rvq_encode(emb, codebooks, dtype=torch.float64):
+    """emb (B,128,T) -> codes (B,n_q,T) int64.  Evaluated in `dtype` (f64: the reference answer a f32 search is judged by;
+    returns also the gap between best and second-best score per search, for near-tie bookkeeping in the tests)."""
+    B, D, T = emb.shape
+    res = emb.permute(0, 2, 1).reshape(B * T, D).to(dtype)
+    codes, gaps = [], []
+    for q in range(codebooks.shape[0]):
+        e = codebooks[q].to(dtype)
+        dist = -(res.pow(2).sum(1, keepdim=True) - 2 * res @ e.t() + e.pow(2).sum(1)[None, :])
+        top2 = dist.topk(2, dim=1)
+        idx = dist.max(dim=1).indices
+        codes.append(idx); gaps.append(top2.values[:, 0] - top2.values[:, 1])
+        res = res - e[idx]
+    codes = torch.stack(codes, 1).view(B, T, -1).permute(0, 2, 1).contiguous()
+    gaps = torch.stack(gaps, 1).view(B, T, -1).permute(0, 2, 1).contiguous()
+    return codes, gaps
+
+
+def encode(wav, W, dtype=torch.float32):
+    """wav (B,1,L) -> codes (B, n_q, L/320) int64 (generate_code.py:48 `torch.cat([e[0] for e in encoded_frames], -1)`)."""
+    return rvq_encode(encoder_embeddings(wav, W), W["codebooks"], dtype)[0]
+
+
+def random_encoder_weights(seed=1, n_q=8, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+
+    def t(*shape, fan=None):
+        fan = fan or (shape[1] * (shape[2] if len(shape) > 2 else 1))
+        return (torch.rand(shape, generator=g) * 2 - 1) * (3.0 / fan) ** 0.5 * scale
+
+    W = {"codebooks": torch.randn(n_q, 1024, 128, generator=g) * 0.5,
+         "enc.conv0.w": t(32, 1, 7), "enc.conv0.b": t(32, fan=100)}
+    C = 32
+    for i, r in enumerate(ENC_RATIOS):
+        W[f"enc.res{i}.c3.w"] = t(C // 2, C, 3); W[f"enc.res{i}.c3.b"] = t(C // 2, fan=100)
+        W[f"enc.res{i}.c1.w"] = t(C, C // 2, 1); W[f"enc.res{i}.c1.b"] = t(C, fan=100)
+        W[f"enc.res{i}.sc.w"] = t(C, C, 1); W[f"enc.res{i}.sc.b"] = t(C, fan=100)
+        W[f"enc.down{i}.w"] = t(2 * C, C, 2 * r); W[f"enc.down{i}.b"] = t(2 * C, fan=100)
+        C *= 2
+    for l in range(2):
+        W[f"enc.lstm.w_ih{l}"] = t(2048, 512); W[f"enc.lstm.w_hh{l}"] = t(2048, 512)
+        W[f"enc.lstm.b_ih{l}"] = t(2048, fan=100); W[f"enc.lstm.b_hh{l}"] = t(2048, fan=100)
+    W["enc.final.w"] = t(128, 512, 7); W["enc.final.b"] = t(128, fan=100)
+    return W
+
+
+def encoder_weights_from_hf(model):
+    """Effective ENCODER weights (+ codebooks) out of a transformers EncodecModel."""
+    def eff(conv):
+        return conv.weight.detach().clone(), conv.bias.detach().clone()
+    L = model.encoder.layers
+    W = {"codebooks": torch.stack([q.codebook.embed.detach().clone() for q in model.quantizer.layers])}
+    W["enc.conv0.w"], W["enc.conv0.b"] = eff(L[0].conv)
+    idx = 1
+    for i in range(4):
+        rb = L[idx]
+        W[f"enc.res{i}.c3.w"], W[f"enc.res{i}.c3.b"] = eff(rb.block[1].conv)
+        W[f"enc.res{i}.c1.w"], W[f"enc.res{i}.c1.b"] = eff(rb.block[3].conv)
+        W[f"enc.res{i}.sc.w"], W[f"enc.res{i}.sc.b"] = eff(rb.shortcut.conv)
+        W[f"enc.down{i}.w"], W[f"enc.down{i}.b"] = eff(L[idx + 2].conv)
+        idx += 3
+    lstm = L[idx].lstm
+    for l in range(2):
+        for n in ("w_ih", "w_hh", "b_ih", "b_hh"):
+            W[f"enc.lstm.{n}{l}"] = getattr(lstm, f"{'weight' if n[0] == 'w' else 'bias'}_{n[2:]}_l{l}").detach().clone()
+    W["enc.final.w"], W["enc.final.b"] = eff(L[idx + 2].conv)
+    return W
 
 
 def random_weights(seed=0, n_q=8, scale=1.0):

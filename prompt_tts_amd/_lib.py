@@ -11,14 +11,14 @@ LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
 
 PT_F32, PT_BF16 = 0, 1
 PT_V_PLAIN, PT_V_CONCAT, PT_V_CONV, PT_V_WFLIP = 0, 1, 2, 3
-PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD, PT_MAP_CAUSAL_REFLECT, PT_MAP_BACK = 0, 1, 2, 3, 4, 5
+PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD, PT_MAP_CAUSAL_REFLECT, PT_MAP_BACK, PT_MAP_STRIDED_REFLECT = 0, 1, 2, 3, 4, 5, 6
 PT_OUT_T, PT_OUT_F32, PT_OUT_F32_ATOMIC = 0, 1, 2
 
 
 class pt_operand(C.Structure):
     _fields_ = [("p", C.c_void_p), ("ld", C.c_int64), ("p2", C.c_void_p), ("ld2", C.c_int64),
                 ("c_split", C.c_int64), ("kind", C.c_int32), ("trans", C.c_int32), ("taps", C.c_int32),
-                ("cin", C.c_int32), ("rowmap", C.c_int32), ("_pad", C.c_int32),
+                ("cin", C.c_int32), ("rowmap", C.c_int32), ("stride", C.c_int32),
                 ("n_out", C.c_int64), ("n_in", C.c_int64)]
 
 
@@ -47,7 +47,7 @@ class pt_rowconv_desc(C.Structure):
                 ("taps", C.c_int32), ("rowmap", C.c_int32), ("elu_x", C.c_int32), ("x2", C.c_void_p), ("ldx2", C.c_int64),
                 ("cin2", C.c_int32), ("elu_x2", C.c_int32), ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
                 ("N", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int64), ("y_f32", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("stride", C.c_int32)]
 
 
 class pt_lstm2_desc(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
                       _i32, _vp],
     "pt_pack_shadow": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pt_rvq_decode": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_rvq_search": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
     "pt_rowconv": [C.POINTER(pt_rowconv_desc), _i32, _vp],
     "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],
     "pt_codes_from_continuous": [_vp, _vp, _i64, _i64, _vp],

@@ -31,10 +31,34 @@ __global__ __launch_bounds__(256) void rvq_kernel(const int64_t* __restrict__ co
   }
 }
 
+// ---- RVQ encode: one stage of the nearest-codeword search (one wave per token) -------------------------------
+__global__ __launch_bounds__(256) void rvq_search_kernel(const float* __restrict__ scores, const float* __restrict__ cb,
+                                                         float* __restrict__ residual, int64_t* __restrict__ codes,
+                                                         int64_t M, int64_t nq, int64_t Tn, int64_t q, int bins, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* sr = scores + m * bins;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int j = lane; j < bins; j += 64) {                   // ascending j: strict '>' keeps the first maximum of this lane
+    const float v = sr[j];
+    if (v > best) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {                  // larger value wins; equal values: smaller index (torch.max)
+    const float ov = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (bi >= bins) bi = 0;                                    // every score NaN: defined output
+  const int64_t b = m / Tn, t = m - b * Tn;
+  if (lane == 0) codes[(b * nq + q) * Tn + t] = bi;
+  for (int d = lane; d < dim; d += 64) residual[m * dim + d] -= cb[(int64_t)bi * dim + d];
+}
+
 // ---- row-streaming conv -----------------------------------------------------------------------------------------
 struct RowConvParams {
   int64_t M; int n_rows;
-  const char* x; int64_t ldx; int cin, taps, rowmap, elu_x;
+  const char* x; int64_t ldx; int cin, taps, rowmap, elu_x, stride, n_in;
   const char* x2; int64_t ldx2; int cin2, elu_x2;
   const char* w; int64_t ldw; const float* bias; int N, act;
   char* y; int64_t ldy; int y_f32;
@@ -89,9 +113,10 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
           const int tap = k0 / p.cin, ci = k0 - tap * p.cin;
           int ns; bool ok;
           if (p.rowmap == PT_MAP_CAUSAL_REFLECT) { const int v = n + tap - (p.taps - 1); ns = v < 0 ? -v : v; ok = ns < p.n_rows; }
+          else if (p.rowmap == PT_MAP_STRIDED_REFLECT) { const int v = n * p.stride + tap - (p.taps - p.stride); ns = v < 0 ? -v : v; ok = ns < p.n_in; }
           else { ns = n - tap; ok = ns >= 0; }                                   // PT_MAP_BACK
           if (ok) {
-            frag_load_global(fa, reinterpret_cast<const T*>(p.x) + (b * p.n_rows + ns) * p.ldx + ci);
+            frag_load_global(fa, reinterpret_cast<const T*>(p.x) + (b * p.n_in + ns) * p.ldx + ci);
             have = true; elu = p.elu_x;
           }
         } else if (mok && p.x2 && k0 - K1 < p.cin2) {
@@ -246,12 +271,24 @@ extern "C" int pt_rvq_decode(const int64_t* codes, const void* codebooks, void* 
   return PT_OK;
 }
 
+extern "C" int pt_rvq_search(const float* scores, const float* codebook, float* residual, int64_t* codes, int64_t B, int64_t n_q,
+                             int64_t T, int64_t q, int64_t bins, int64_t dim, pt_stream stream) {
+  if (B <= 0 || n_q <= 0 || T <= 0 || q < 0 || q >= n_q || bins <= 0 || bins > (1 << 30) || dim <= 0) return PT_ERR_SHAPE;
+  if (!scores || !codebook || !residual || !codes) return PT_ERR_ARG;
+  const int64_t M = B * T;
+  hipLaunchKernelGGL(rvq_search_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, codebook,
+                     residual, codes, M, n_q, T, q, (int)bins, (int)dim);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
 extern "C" int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
   if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
   const int es = dtype == PT_F32 ? 4 : 2;
   if (d->B <= 0 || d->n_rows <= 0 || d->N <= 0 || d->N > 64 || d->cin <= 0 || d->cin % 8 != 0 || d->taps < 1) return PT_ERR_SHAPE;
-  if (d->rowmap != PT_MAP_CAUSAL_REFLECT && d->rowmap != PT_MAP_BACK) return PT_ERR_ARG;
+  if (d->rowmap != PT_MAP_CAUSAL_REFLECT && d->rowmap != PT_MAP_BACK && d->rowmap != PT_MAP_STRIDED_REFLECT) return PT_ERR_ARG;
+  if (d->rowmap == PT_MAP_STRIDED_REFLECT && (d->stride < 1 || d->taps < d->stride || d->n_rows * d->stride < d->taps)) return PT_ERR_SHAPE;
   if (d->rowmap == PT_MAP_CAUSAL_REFLECT && d->n_rows < d->taps) return PT_ERR_SHAPE;
   if (d->x2 && (d->cin2 <= 0 || d->cin2 % 8 != 0)) return PT_ERR_SHAPE;
   const int64_t K = (int64_t)d->taps * d->cin + (d->x2 ? d->cin2 : 0);
@@ -262,6 +299,7 @@ extern "C" int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream)
   RowConvParams p;
   p.M = d->B * d->n_rows; p.n_rows = (int)d->n_rows;
   p.x = (const char*)d->x; p.ldx = d->ldx; p.cin = d->cin; p.taps = d->taps; p.rowmap = d->rowmap; p.elu_x = d->elu_x;
+  p.stride = d->rowmap == PT_MAP_STRIDED_REFLECT ? d->stride : 1; p.n_in = p.n_rows * p.stride;
   p.x2 = (const char*)d->x2; p.ldx2 = d->ldx2; p.cin2 = d->x2 ? d->cin2 : 0; p.elu_x2 = d->elu_x2;
   p.w = (const char*)d->w; p.ldw = d->ldw; p.bias = d->bias; p.N = d->N; p.act = d->act;
   p.y = (char*)d->y; p.ldy = d->ldy; p.y_f32 = d->y_f32;

@@ -29,7 +29,7 @@ namespace {
 struct VOp {
   const char* p; const char* p2;
   int64_t ld, ld2, c_split;
-  int kind, taps, cin, rowmap;
+  int kind, taps, cin, rowmap, stride;
   int n_out, n_in;
   int cin_shift, nout_shift;   // log2 when a power of two, else -1
   int seg_kt;                  // k-tiles over which a chunk's address advances by `step` bytes per k-tile (1: recompute always)
@@ -86,6 +86,7 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
       case PT_MAP_UP2: ns = u >> 1; ok = (u >= 0) && (u < 2 * op.n_in); break;
       case PT_MAP_S2_DGRAD: ns = u >> 1; ok = (u >= 0) && ((u & 1) == 0) && (ns < op.n_in); break;
       case PT_MAP_CAUSAL_REFLECT: { const int v = n + tap - (op.taps - 1); ns = v < 0 ? -v : v; ok = ns < op.n_in; } break;
+      case PT_MAP_STRIDED_REFLECT: { const int v = n * op.stride + tap - (op.taps - op.stride); ns = v < 0 ? -v : v; ok = ns < op.n_in; } break;
       default: /* PT_MAP_BACK */ ns = n - tap; ok = ns >= 0; break;
     }
     if (!ok) return zero;
@@ -702,7 +703,7 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
   VOp v;
   v.p = reinterpret_cast<const char*>(o.p); v.p2 = reinterpret_cast<const char*>(o.p2);
   v.ld = o.ld; v.ld2 = o.ld2; v.c_split = o.c_split;
-  v.kind = o.kind; v.taps = o.taps; v.cin = o.cin > 0 ? o.cin : 1; v.rowmap = o.rowmap;
+  v.kind = o.kind; v.taps = o.taps; v.cin = o.cin > 0 ? o.cin : 1; v.rowmap = o.rowmap; v.stride = o.stride > 0 ? o.stride : 1;
   v.n_out = (int)(o.n_out > 0 ? o.n_out : 1); v.n_in = (int)o.n_in;
   auto lg = [](int x) { return (x > 0 && (x & (x - 1)) == 0) ? __builtin_ctz(x) : -1; };
   v.cin_shift = lg(v.cin); v.nout_shift = lg(v.n_out);
@@ -738,7 +739,8 @@ int check_operand(const pt_operand& o, int esize) {
   } else if (o.kind == PT_V_CONV) {
     if (o.taps < 1 || o.taps > 16) return PT_ERR_ARG;
     if (o.cin <= 0 || (o.cin * esize) % 16 != 0 || o.n_out <= 0 || o.n_in <= 0) return PT_ERR_SHAPE;
-    if (o.rowmap < PT_MAP_S1 || o.rowmap > PT_MAP_BACK) return PT_ERR_ARG;
+    if (o.rowmap < PT_MAP_S1 || o.rowmap > PT_MAP_STRIDED_REFLECT) return PT_ERR_ARG;
+    if (o.rowmap == PT_MAP_STRIDED_REFLECT && (o.stride < 1 || o.taps < o.stride || o.n_in < o.taps)) return PT_ERR_SHAPE;
     if (o.rowmap == PT_MAP_CAUSAL_REFLECT && o.n_in < o.taps) return PT_ERR_SHAPE;   // reflect needs n_in > pad
   } else if (o.kind == PT_V_WFLIP) {
     if (o.cin <= 0) return PT_ERR_SHAPE;

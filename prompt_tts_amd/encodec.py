@@ -167,3 +167,161 @@ class EncodecDecoder:
         wav = torch.empty(B * n, 1, dtype=torch.float32, device=self.device)
         self._rowconv(B, n, xe, 32, 7, L.PT_MAP_CAUSAL_REFLECT, self.wfin, self.bfin, 1, wav, y_f32=True)
         return wav.view(B, 1, n)
+
+
+# =====================================================================================================================
+# ENCODE: waveform -> codes (reference: data_preparation/generate_code.py:45-51, encodec `model.encode`; SURVEY a-12)
+# =====================================================================================================================
+ENC_RATIOS = (2, 4, 5, 8)
+ENC_WEIGHT_KEYS = ["codebooks", "enc.conv0.w", "enc.conv0.b"] + \
+    [f"enc.res{i}.{c}.{s}" for i in range(4) for c in ("c3", "c1", "sc") for s in ("w", "b")] + \
+    [f"enc.down{i}.{s}" for i in range(4) for s in ("w", "b")] + \
+    [f"enc.lstm.{n}{l}" for l in range(2) for n in ("w_ih", "w_hh", "b_ih", "b_hh")] + ["enc.final.w", "enc.final.b"]
+
+
+def encoder_weights_from_encodec_state_dict(sd, n_q=8):
+    """Map an `encodec.EncodecModel.state_dict()` (original package naming) to effective ENCODER weights + codebooks."""
+    def conv(prefix):
+        return fold_weight_norm(sd[prefix + ".weight_g"], sd[prefix + ".weight_v"], 0), sd[prefix + ".bias"]
+    W = {"codebooks": torch.stack([sd[f"quantizer.vq.layers.{q}._codebook.embed"] for q in range(n_q)])}
+    W["enc.conv0.w"], W["enc.conv0.b"] = conv("encoder.model.0.conv.conv")
+    idx = 1
+    for i in range(4):
+        rb = f"encoder.model.{idx}"
+        W[f"enc.res{i}.c3.w"], W[f"enc.res{i}.c3.b"] = conv(rb + ".block.1.conv.conv")
+        W[f"enc.res{i}.c1.w"], W[f"enc.res{i}.c1.b"] = conv(rb + ".block.3.conv.conv")
+        W[f"enc.res{i}.sc.w"], W[f"enc.res{i}.sc.b"] = conv(rb + ".shortcut.conv.conv")
+        W[f"enc.down{i}.w"], W[f"enc.down{i}.b"] = conv(f"encoder.model.{idx + 2}.conv.conv")
+        idx += 3
+    for l in range(2):
+        for n, k in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
+            W[f"enc.lstm.{n}{l}"] = sd[f"encoder.model.{idx}.lstm.{k}_l{l}"]
+    W["enc.final.w"], W["enc.final.b"] = conv(f"encoder.model.{idx + 2}.conv.conv")
+    return W
+
+
+class EncodecEncoder:
+    """SEANet encoder + residual vector quantiser on the HIP kernels, token-major.  conv k7 1->32 and the 32/64-channel
+    layers (the 24 kHz end, HBM-bound) run on the row-streaming kernel, everything from 128 channels on pt_gemm with the
+    strided causal-reflect row map (implicit GEMM: no im2col, no padded copies); the LSTM is the decoder's; each RVQ stage
+    is an exact-f32 GEMM (scores = 2 x.e - |e|^2) plus a one-wave-per-token argmax / residual-update kernel.
+    The default dtype is float32: code indices are decided by gaps far below bf16 resolution."""
+    sample_rate = 24000
+    hop = 320
+
+    def __init__(self, weights, device="cuda", dtype=torch.float32):
+        missing = [k for k in ENC_WEIGHT_KEYS if k not in weights]
+        if missing:
+            raise KeyError(f"missing encoder weights: {missing[:4]}...")
+        self.device, self.dtype, self.pt = torch.device(device), dtype, ops._DT[dtype]
+        W = {k: v.detach().float().cpu() for k, v in weights.items()}
+        d = lambda t: t.to(self.device, dtype).contiguous()
+        f = lambda t: t.to(self.device, torch.float32).contiguous()
+        self.n_q = W["codebooks"].shape[0]
+        self.cb = f(W["codebooks"])                                     # (n_q, 1024, 128) f32
+        self.cb_bias = f(-(W["codebooks"] ** 2).sum(-1))                # -|e|^2
+        w0 = torch.zeros(32, 7, 8); w0[:, :, 0] = W["enc.conv0.w"][:, 0, :]          # the sample sits in channel 0 of 8
+        self.w0, self.b0 = d(_pad_cols(w0.reshape(32, 56), 32)), f(W["enc.conv0.b"])
+        self.stages = []
+        Cc = 32
+        for i, r in enumerate(ENC_RATIOS):
+            c3 = _conv_mat(W[f"enc.res{i}.c3.w"])
+            fused = torch.cat([W[f"enc.res{i}.c1.w"][:, :, 0], W[f"enc.res{i}.sc.w"][:, :, 0]], dim=1)
+            dn = _conv_mat(W[f"enc.down{i}.w"])                          # [2C][2r*C], column = tap*C + ci
+            small = Cc <= 64                      # residual block on the row-streaming kernel
+            small_dn = 2 * Cc <= 64               # strided conv on the row-streaming kernel
+            self.stages.append(dict(
+                r=r, C=Cc, small=small, small_dn=small_dn,
+                w3=d(_pad_cols(c3, 32) if small else c3), b3=f(W[f"enc.res{i}.c3.b"]),
+                wf=d(_pad_cols(fused, 32) if small else fused), bf=f(W[f"enc.res{i}.c1.b"] + W[f"enc.res{i}.sc.b"]),
+                wd=d(_pad_cols(dn, 32) if small_dn else dn), bd=f(W[f"enc.down{i}.b"])))
+            Cc *= 2
+        self.w_ih0 = d(W["enc.lstm.w_ih0"]); self.bias0 = f(W["enc.lstm.b_ih0"] + W["enc.lstm.b_hh0"])
+        self.w_hh0 = d(W["enc.lstm.w_hh0"])
+        self.wcat1 = d(torch.cat([W["enc.lstm.w_ih1"], W["enc.lstm.w_hh1"]], dim=1))
+        self.bias1 = f(W["enc.lstm.b_ih1"] + W["enc.lstm.b_hh1"])
+        self.wfin, self.bfin = d(_conv_mat(W["enc.final.w"])), f(W["enc.final.b"])
+
+    _rowconv = EncodecDecoder._rowconv
+    _empty = EncodecDecoder._empty
+
+    def _rowconv_strided(self, Bn, n_out, x, cin, taps, stride, w, bias, N, y):
+        d = L.pt_rowconv_desc()
+        d.B, d.n_rows = Bn, n_out
+        d.x, d.ldx, d.cin, d.taps, d.rowmap, d.elu_x, d.stride = x.data_ptr(), x.stride(0), cin, taps, L.PT_MAP_STRIDED_REFLECT, 0, stride
+        d.w, d.ldw, d.bias, d.N, d.act = w.data_ptr(), w.stride(0), bias.data_ptr(), N, 0
+        d.y, d.ldy, d.y_f32 = y.data_ptr(), y.stride(0), 0
+        check(lib.pt_rowconv(C.byref(d), self.pt, ops._stream()), "pt_rowconv")
+
+    @torch.no_grad()
+    def embeddings(self, wav):
+        """wav (B, 1, L) f32, L a multiple of 320 -> (B*T, 128) f32 token-major embeddings, T = L / 320."""
+        if wav.dim() != 3 or wav.shape[1] != 1:
+            raise ValueError("wav must be (B, 1, L)")
+        B, _, Ln = wav.shape
+        if Ln % self.hop != 0 or Ln < 7 * self.hop:
+            raise ValueError("the length must be a multiple of 320 samples and at least 7 frames")
+        pt = self.pt
+        x0 = torch.zeros(B * Ln, 8, dtype=self.dtype, device=self.device)
+        x0[:, 0] = wav.to(self.device, self.dtype).reshape(-1)
+        n = Ln
+        cur = self._empty(B * n, 32)
+        self._rowconv(B, n, x0, 8, 7, L.PT_MAP_CAUSAL_REFLECT, self.w0, self.b0, 32, cur)
+        cur_e = None                         # ELU(cur) when the producer could write it as a second output
+        for i, st in enumerate(self.stages):
+            r, Cc = st["r"], st["C"]
+            M = B * n
+            c3e = self._empty(M, Cc // 2); oute = self._empty(M, Cc)
+            if st["small"]:
+                self._rowconv(B, n, cur, Cc, 3, L.PT_MAP_CAUSAL_REFLECT, st["w3"], st["b3"], Cc // 2, c3e, act=1, elu_x=1)
+                self._rowconv(B, n, c3e, Cc // 2, 1, L.PT_MAP_BACK, st["wf"], st["bf"], Cc, oute, act=1, x2=cur, cin2=Cc)
+            else:
+                ops.gemm(M, Cc // 2, 3 * Cc, ops.conv(cur_e, Cc, n, n, L.PT_MAP_CAUSAL_REFLECT, taps=3), ops.plain(st["w3"]), c3e, pt,
+                         bias=st["b3"], act=1)
+                ops.gemm(M, Cc, Cc // 2 + Cc, ops.concat(c3e, cur), ops.plain(st["wf"]), oute, pt, bias=st["bf"], act=1)
+            n_out = n // r
+            nxt = self._empty(B * n_out, 2 * Cc)
+            nxt_e = None
+            if st["small_dn"]:
+                self._rowconv_strided(B, n_out, oute, Cc, 2 * r, r, st["wd"], st["bd"], 2 * Cc, nxt)
+            else:
+                need_e = i + 1 < len(self.stages) and not self.stages[i + 1]["small"]   # next residual block runs on pt_gemm: it reads ELU(x)
+                if need_e:
+                    nxt_e = self._empty(B * n_out, 2 * Cc)
+                ops.gemm(B * n_out, 2 * Cc, 2 * r * Cc, ops.conv(oute, Cc, n_out, n, L.PT_MAP_STRIDED_REFLECT, taps=2 * r, stride=r),
+                         ops.plain(st["wd"]), nxt, pt, bias=st["bd"], out2=nxt_e, ldc2=2 * Cc, act2=1)
+            cur, cur_e, n = nxt, nxt_e, n_out
+        T = n
+        M = B * T
+        xg0 = self._empty(M, 2048)
+        ops.gemm(M, 2048, 512, ops.plain(cur), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
+        h0 = self._empty(M, 512); h1 = self._empty(M, 512); ze = self._empty(M, 512)
+        c0 = torch.empty(B, 512, dtype=torch.float32, device=self.device); c1 = torch.empty_like(c0)
+        ld = L.pt_lstm2_desc()
+        ld.B, ld.T, ld.H = B, T, 512
+        ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = cur.data_ptr(), xg0.data_ptr(), self.w_hh0.data_ptr(), self.wcat1.data_ptr(), self.bias1.data_ptr()
+        ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
+        check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
+        emb = torch.empty(M, 128, dtype=torch.float32, device=self.device)
+        ops.gemm(M, 128, 7 * 512, ops.conv(ze, 512, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.wfin), emb, pt,
+                 bias=self.bfin, out_kind=L.PT_OUT_F32 if self.dtype != torch.float32 else L.PT_OUT_T)
+        return emb, B, T
+
+    @torch.no_grad()
+    def quantize(self, emb, B, T):
+        """emb (B*T, 128) f32 -> codes (B, n_q, T) int64: n_q stages of exact-f32 scores GEMM + argmax / residual update."""
+        M = B * T
+        res = emb.clone()
+        codes = torch.empty(B, self.n_q, T, dtype=torch.int64, device=self.device)
+        scores = torch.empty(M, 1024, dtype=torch.float32, device=self.device)
+        for q in range(self.n_q):
+            ops.gemm(M, 1024, 128, ops.plain(res), ops.plain(self.cb[q]), scores, L.PT_F32, bias=self.cb_bias[q], alpha=2.0)
+            check(lib.pt_rvq_search(scores.data_ptr(), self.cb[q].data_ptr(), res.data_ptr(), codes.data_ptr(), B, self.n_q, T, q,
+                                    1024, 128, ops._stream()), "pt_rvq_search")
+        return codes
+
+    @torch.no_grad()
+    def encode(self, wav):
+        """wav (B, 1, L) f32 -> codes (B, n_q, L/320) int64 (generate_code.py:48)."""
+        emb, B, T = self.embeddings(wav)
+        return self.quantize(emb, B, T)

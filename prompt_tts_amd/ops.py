@@ -51,10 +51,10 @@ def concat(t1, t2, trans=False):
     return o
 
 
-def conv(t, cin, n_out, n_in, rowmap=L.PT_MAP_S1, taps=3, trans=False):
+def conv(t, cin, n_out, n_in, rowmap=L.PT_MAP_S1, taps=3, trans=False, stride=1):
     o = L.pt_operand()
     o.p = t.data_ptr(); o.ld = t.stride(0); o.kind = L.PT_V_CONV; o.trans = int(trans)
-    o.taps = taps; o.cin = cin; o.rowmap = rowmap; o.n_out = n_out; o.n_in = n_in
+    o.taps = taps; o.cin = cin; o.rowmap = rowmap; o.n_out = n_out; o.n_in = n_in; o.stride = stride
     return o
 
 

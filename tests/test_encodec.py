@@ -1,4 +1,4 @@
-"""Encodec decode: oracle vs the installed transformers EncodecModel (CPU), HIP decoder vs oracle (GPU)."""
+"""Encodec decode and encode: oracle vs the installed transformers EncodecModel (CPU), HIP decoder / encoder vs oracle (GPU)."""
 import pytest
 import torch
 
@@ -85,3 +85,111 @@ def test_hip_decoder_batch_items_independent(dev):
     assert float((full[2:3] - one).abs().max()) < 1e-4 * float(full.abs().max())
     pre = dec.decode(codes[:, :, :120])                       # causal: a prefix decodes to the prefix of the waveform
     assert float((full[:, :, :320 * 120] - pre).abs().max()) < 1e-4 * float(full.abs().max())
+
+
+# ---- encode (SURVEY a-12) ---------------------------------------------------------------------------------------------
+def _hf_with_weights(W):
+    """transformers EncodecModel carrying the effective encoder weights W (weight-norm parametrisation: v = w, g = |w|)."""
+    from transformers import EncodecConfig, EncodecModel
+    m = EncodecModel(EncodecConfig()).eval()
+
+    def put(conv, w, b):
+        with torch.no_grad():
+            par = conv.parametrizations.weight
+            par.original1.copy_(w); par.original0.copy_(w.flatten(1).norm(dim=1).view(-1, 1, 1)); conv.bias.copy_(b)
+    Ls = m.encoder.layers
+    put(Ls[0].conv, W["enc.conv0.w"], W["enc.conv0.b"])
+    idx = 1
+    for i in range(4):
+        rb = Ls[idx]
+        put(rb.block[1].conv, W[f"enc.res{i}.c3.w"], W[f"enc.res{i}.c3.b"])
+        put(rb.block[3].conv, W[f"enc.res{i}.c1.w"], W[f"enc.res{i}.c1.b"])
+        put(rb.shortcut.conv, W[f"enc.res{i}.sc.w"], W[f"enc.res{i}.sc.b"])
+        put(Ls[idx + 2].conv, W[f"enc.down{i}.w"], W[f"enc.down{i}.b"])
+        idx += 3
+    lstm = Ls[idx].lstm
+    with torch.no_grad():
+        for l in range(2):
+            for n in ("w_ih", "w_hh", "b_ih", "b_hh"):
+                getattr(lstm, f"{'weight' if n[0] == 'w' else 'bias'}_{n[2:]}_l{l}").copy_(W[f"enc.lstm.{n}{l}"])
+        for q in range(W["codebooks"].shape[0]):
+            m.quantizer.layers[q].codebook.embed.copy_(W["codebooks"][q])
+    put(Ls[idx + 2].conv, W["enc.final.w"], W["enc.final.b"])
+    return m
+
+
+def test_encode_oracle_matches_transformers_encodec_cpu():
+    """The restated encoder + RVQ search against the independent implementation, with O(1) activations and varied codes."""
+    from oracle import encodec as oe
+    W = oe.random_encoder_weights(5)
+    m = _hf_with_weights(W)
+    wav = torch.randn(2, 1, 320 * 24, generator=torch.Generator().manual_seed(2)) * 0.5
+    with torch.no_grad():
+        want_emb = m.encoder(wav)
+        want_codes = m.encode(wav, bandwidth=6.0).audio_codes[0]
+    emb = oe.encoder_embeddings(wav, W)
+    assert emb.shape == (2, 128, 24)
+    assert float((emb - want_emb).abs().max()) < 1e-5 * float(want_emb.abs().max())
+    codes = oe.encode(wav, W)
+    assert codes.shape == (2, 8, 24) and codes.dtype == torch.int64
+    assert torch.equal(codes, want_codes)
+    assert codes.unique().numel() > 100                      # a real search, not a constant answer
+    c64, gaps = oe.rvq_encode(emb, W["codebooks"], torch.float64)
+    assert torch.equal(c64, codes) and float(gaps.min()) > 0
+    with pytest.raises(ValueError):
+        oe.encoder_embeddings(torch.zeros(1, 1, 321), W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(2, 24), (3, 50)])
+def test_hip_encoder_vs_oracle(dev, B, T):
+    """f32: embeddings within 1e-3; the search is bit-exact given its input (codes == f64 search of the device embeddings,
+    except where the f64 runner-up is within 1e-4 of the winner); end-to-end code agreement with the oracle reported."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecEncoder
+    W = oe.random_encoder_weights(5)
+    wav = torch.randn(B, 1, 320 * T, generator=torch.Generator().manual_seed(10 * B + T)) * 0.5
+    enc = EncodecEncoder(W, device=dev, dtype=torch.float32)
+    emb, b, t = enc.embeddings(wav.to(dev))
+    want = oe.encoder_embeddings(wav, W)                                   # (B,128,T)
+    got = emb.view(B, T, 128).permute(0, 2, 1).cpu()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 1e-3, err
+    codes = enc.quantize(emb, b, t).cpu()
+    assert codes.shape == (B, 8, T) and codes.dtype == torch.int64
+    ref, gaps = oe.rvq_encode(got, W["codebooks"], torch.float64)          # same input, reference arithmetic
+    # a token's later stages depend on its earlier choices: compare up to and including the first disagreement
+    bad = codes != ref
+    first_bad = bad.int().argmax(dim=1, keepdim=True)                      # (B,1,T) stage of the first disagreement (0 if none)
+    any_bad = bad.any(dim=1, keepdim=True)
+    g_at = gaps.gather(1, first_bad)
+    assert bool(((~any_bad) | (g_at < 1e-4)).all()), "search disagrees away from a near-tie"
+    assert float(any_bad.float().mean()) < 0.01
+    e2e = oe.encode(wav, W)
+    assert float((codes == e2e).float().mean()) > 0.97                     # embeddings differ by ~1e-6: only near-ties flip
+
+
+@pytest.mark.gpu
+def test_hip_encoder_causal_and_batch_independent(dev):
+    """Size-independent properties at a longer length: items are independent; a prefix encodes to the prefix of the codes."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecEncoder
+    enc = EncodecEncoder(oe.random_encoder_weights(6), device=dev, dtype=torch.float32)
+    wav = (torch.randn(3, 1, 320 * 150, generator=torch.Generator().manual_seed(3)) * 0.5).to(dev)
+    full = enc.encode(wav)
+    assert torch.equal(enc.encode(wav[1:2]), full[1:2])
+    assert torch.equal(enc.encode(wav[:, :, :320 * 90]), full[:, :, :90])
+    with pytest.raises(ValueError):
+        enc.encode(wav[:, :, :321])
+
+
+@pytest.mark.gpu
+def test_hip_encoder_bf16_embeddings(dev):
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecEncoder
+    W = oe.random_encoder_weights(5)
+    wav = torch.randn(2, 1, 320 * 30, generator=torch.Generator().manual_seed(4)) * 0.5
+    emb, B, T = EncodecEncoder(W, device=dev, dtype=torch.bfloat16).embeddings(wav.to(dev))
+    want = oe.encoder_embeddings(wav, W)
+    err = float((emb.view(B, T, 128).permute(0, 2, 1).cpu() - want).abs().max() / want.abs().max())
+    assert err < 8e-2, err
