@@ -134,6 +134,22 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
             "weights": "seeded random (no checkpoint offline)"}
 
 
+def encode_bench(dev, prompts=32, seconds=12, iters=3):
+    """Encodec ENCODE leg (generate_code.py defaults: batch 32, 12 s windows at 24 kHz -> 900 frames), f32, seeded weights."""
+    import encode_codec
+    enc = encode_codec.load_encoder(None, torch.float32, dev)
+    wav = (torch.randn(prompts, 1, 24000 * seconds, generator=torch.Generator().manual_seed(7)) * 0.3).to(dev)
+    enc.encode(wav); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        codes = enc.encode(wav)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"metric": "encoded-audio-seconds/sec (Encodec 24 kHz encode + 8-stage RVQ search)", "value": prompts * seconds / dt,
+            "unit": "audio-s/s", "ms_per_batch": dt * 1e3, "prompts": prompts, "frames": int(codes.shape[-1]), "dtype": "f32",
+            "weights": "seeded random (no checkpoint offline)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +285,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_decode:
         note("decode leg (configs[3]: 64 prompts x 1024 frames)")
         out["decode"] = decode_bench(dev)
+        note("encode leg (32 waveforms x 12 s)")
+        out["encode"] = encode_bench(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl, S)
     if rank == 0:

@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Waveform -> codec codes, with the reference's surface (data_preparation/generate_code.py:18-103): `create_batch`,
+`generate(batch)` and `python encode_codec.py --input_file x.tar` writing x_processed.tar with `<utt>.npy` (int64 [8, T]) and
+`<utt>.len.txt` next to the text files.  The encoder + residual vector quantiser run on the MI355X kernels
+(prompt_tts_amd/encodec.py: EncodecEncoder).
+
+The reference builds `EncodecModel.encodec_model_24khz()` at import time (downloads pretrained weights) and reads audio with
+torchaudio; this build never fetches anything and has no torchaudio: pass `--weights <encodec state_dict .pt>` (original
+`encodec` package naming; weight_g / weight_v are folded on load; a seeded random encoder otherwise, useful only for plumbing)
+and 24 kHz PCM-16 WAV members (read with the stdlib `wave` module; stereo keeps its first channel as the reference does).
+"""
+import io
+import tarfile
+import wave
+from argparse import ArgumentParser
+from os.path import abspath
+from tempfile import TemporaryDirectory
+
+import numpy as np
+import torch
+
+from prompt_tts_amd.encodec import EncodecEncoder, encoder_weights_from_encodec_state_dict
+
+SAMPLE_RATE = 24000
+_model = None
+
+
+def random_encoder_weights(seed=1, n_q=8):
+    """Seeded fan-in-scaled weights of the 24 kHz encoder architecture (no checkpoint is available offline)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def t(*shape, fan=None):
+        fan = fan or (shape[1] * (shape[2] if len(shape) > 2 else 1))
+        return (torch.rand(shape, generator=g) * 2 - 1) * (3.0 / fan) ** 0.5
+
+    W = {"codebooks": torch.randn(n_q, 1024, 128, generator=g) * 0.5, "enc.conv0.w": t(32, 1, 7), "enc.conv0.b": t(32, fan=100)}
+    C = 32
+    for i, r in enumerate((2, 4, 5, 8)):
+        W[f"enc.res{i}.c3.w"] = t(C // 2, C, 3); W[f"enc.res{i}.c3.b"] = t(C // 2, fan=100)
+        W[f"enc.res{i}.c1.w"] = t(C, C // 2, 1); W[f"enc.res{i}.c1.b"] = t(C, fan=100)
+        W[f"enc.res{i}.sc.w"] = t(C, C, 1); W[f"enc.res{i}.sc.b"] = t(C, fan=100)
+        W[f"enc.down{i}.w"] = t(2 * C, C, 2 * r); W[f"enc.down{i}.b"] = t(2 * C, fan=100)
+        C *= 2
+    for l in range(2):
+        W[f"enc.lstm.w_ih{l}"] = t(2048, 512); W[f"enc.lstm.w_hh{l}"] = t(2048, 512)
+        W[f"enc.lstm.b_ih{l}"] = t(2048, fan=100); W[f"enc.lstm.b_hh{l}"] = t(2048, fan=100)
+    W["enc.final.w"] = t(128, 512, 7); W["enc.final.b"] = t(128, fan=100)
+    return W
+
+
+def load_encoder(weights_path=None, dtype=torch.float32, device="cuda", seed=1):
+    global _model
+    if weights_path is not None:
+        W = encoder_weights_from_encodec_state_dict(torch.load(weights_path, map_location="cpu"))
+    else:
+        W = random_encoder_weights(seed)
+    _model = EncodecEncoder(W, device=device, dtype=dtype)
+    return _model
+
+
+def read_wav(fileobj):
+    """24 kHz PCM-16 WAV -> float tensor (1, n) in [-1, 1) (first channel of a stereo file, generate_code.py:27-28)."""
+    with wave.open(fileobj, "rb") as w:
+        if w.getframerate() != SAMPLE_RATE or w.getsampwidth() != 2:
+            raise ValueError(f"expected {SAMPLE_RATE} Hz PCM-16 audio (no resampler in this build), got "
+                             f"{w.getframerate()} Hz / {8 * w.getsampwidth()} bit")
+        ch = w.getnchannels()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, ch)[:, 0]
+    return torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None, :]
+
+
+def create_batch(members, tf, batch_size, max_duration):
+    """Yield [wavs (1,1,L) padded to max_duration seconds, member names, code lengths ceil(n/320)] (generate_code.py:18-42)."""
+    index = 1
+    batch = [[], [], []]
+    for member in members:
+        if ".wav" not in member.name:
+            continue
+        wav = read_wav(io.BytesIO(tf.extractfile(member).read()))
+        if wav.shape[1] > SAMPLE_RATE * max_duration:
+            raise ValueError(f"{member.name} is longer than max_duration={max_duration}s")
+        batch[1].append(member.name)
+        batch[2].append(np.ceil(wav.shape[1] / 320))
+        wav = torch.cat([wav, torch.zeros((1, SAMPLE_RATE * max_duration - wav.shape[1]))], dim=-1)
+        batch[0].append(wav.unsqueeze(0))
+        if index % batch_size == 0:
+            yield batch
+            batch = [[], [], []]
+        index += 1
+    if len(batch[0]) != 0:
+        yield batch
+
+
+def generate(batch):
+    """list of (1, 1, L) waveforms -> numpy int64 codes (B, 8, L/320) (generate_code.py:45-51)."""
+    model = _model if _model is not None else load_encoder()
+    wav = torch.cat(batch)
+    return model.encode(wav).cpu().numpy()
+
+
+def main(input_file, batch_size, max_duration):
+    output_file = input_file.replace(".tar", "_processed.tar")
+    tf = tarfile.open(input_file, "r")
+    members = tf.getmembers()
+    output_tf = tarfile.open(output_file, "w")
+    for batch in create_batch(members, tf, batch_size, max_duration):
+        codes = generate(batch[0])
+        with TemporaryDirectory() as dirname:
+            for i, code in enumerate(codes):
+                np_file = batch[1][i].replace(".wav", ".npy").split('/')[-1]
+                np.save(abspath(f"{dirname}/{np_file}"), code)
+                output_tf.add(abspath(f"{dirname}/{np_file}"), arcname=np_file)
+                len_file = np_file.replace(".npy", ".len.txt")
+                with open(abspath(f"{dirname}/{len_file}"), "w") as f:
+                    f.write(str(batch[2][i]))
+                output_tf.add(abspath(f"{dirname}/{len_file}"), arcname=len_file)
+    with TemporaryDirectory() as dirname:                         # text members travel unchanged
+        for member in members:
+            if ".txt" in member.name:
+                tf.extract(member, dirname)
+                output_tf.add(abspath(f"{dirname}/{member.name}"), arcname=member.name.split('/')[-1])
+    tf.close()
+    output_tf.close()
+    return output_file
+
+
+def parse_args():
+    parser = ArgumentParser(description="Generate codec codes of waveforms (WebDataset-style tar in, tar out).")
+    parser.add_argument("--input_file", type=str, required=True, help="Path to the input tar (24 kHz PCM-16 .wav + .txt members).")
+    parser.add_argument("--batch_size", type=int, default=32, help="Batch size of the Encodec encode.")
+    parser.add_argument("--max_duration", type=int, default=12, help="Every waveform is zero-padded to this many seconds.")
+    parser.add_argument("--weights", type=str, default=None, help="encodec state_dict (.pt); seeded random weights otherwise")
+    parser.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    return parser.parse_args()
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    load_encoder(args.weights, torch.float32 if args.dtype == "f32" else torch.bfloat16)
+    print(main(args.input_file, args.batch_size, args.max_duration))

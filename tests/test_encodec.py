@@ -140,6 +140,44 @@ def test_encode_oracle_matches_transformers_encodec_cpu():
         oe.encoder_embeddings(torch.zeros(1, 1, 321), W)
 
 
+def test_encode_codec_tar_plumbing_cpu(tmp_path):
+    """encode_codec.py keeps generate_code.py's on-disk format: <utt>.npy int64 [8,T], <utt>.len.txt = ceil(n/320), texts copied."""
+    import io, tarfile, wave
+    import numpy as np
+    import encode_codec as ec
+    tarp = str(tmp_path / "x.tar")
+    rng = np.random.default_rng(0)
+    with tarfile.open(tarp, "w") as tf:
+        for i, n in enumerate((5000, 7777)):
+            buf = io.BytesIO()
+            with wave.open(buf, "wb") as w:
+                w.setnchannels(2 if i else 1); w.setsampwidth(2); w.setframerate(24000)
+                w.writeframes((rng.standard_normal(n * (2 if i else 1)) * 3000).astype("<i2").tobytes())
+            for name, data in ((f"utt{i}.wav", buf.getvalue()), (f"utt{i}.txt", f"hello {i}".encode())):
+                ti = tarfile.TarInfo(name); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+
+    class Fake:                                         # the tar / wav plumbing is host code; the encoder itself is GPU-only
+        def encode(self, wav):
+            assert wav.shape == (2, 1, 24000) and float(wav.abs().max()) < 1.0
+            return torch.arange(wav.shape[0] * 8 * 75).view(wav.shape[0], 8, 75)
+    old = ec._model
+    ec._model = Fake()
+    try:
+        out = ec.main(tarp, 2, 1)
+    finally:
+        ec._model = old
+    with tarfile.open(out) as tf:
+        assert sorted(m.name for m in tf.getmembers()) == ["utt0.len.txt", "utt0.npy", "utt0.txt", "utt1.len.txt", "utt1.npy", "utt1.txt"]
+        assert tf.extractfile("utt1.len.txt").read() == b"25.0" and tf.extractfile("utt0.txt").read() == b"hello 0"
+        code = np.load(io.BytesIO(tf.extractfile("utt1.npy").read()))
+        assert code.dtype == np.int64 and code.shape == (8, 75) and code[0, 0] == 600
+    with pytest.raises(ValueError):                     # no resampler in this build: other rates are refused, not mangled
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(b"\0\0" * 10)
+        buf.seek(0); ec.read_wav(buf)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T", [(2, 24), (3, 50)])
 def test_hip_encoder_vs_oracle(dev, B, T):
