@@ -1,0 +1,58 @@
+"""train.py: reference-compatible checkpoint files, and the resume the reference never wrote."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _config(epochs):
+    return {"cmu_vocab_len": 149, "cmu_seq_len": 64, "cross_attention_dim": 256, "attention_head_dim": 64,
+            "text_encoder_dropout": 0.0, "text_encoder_layers": 1, "sample_size": 64, "in_channels": 8, "out_channels": 8,
+            "layers_per_block": 1, "block_out_channels": [256, 256],      # UNet heads are C/8 wide: 32 is the narrowest
+            "down_block_types": ["CrossAttnDownBlock1D", "DownBlock1D"], "mid_block_type": "UNetMidBlock1DCrossAttn",
+            "up_block_types": ["UpBlock1D", "CrossAttnUpBlock1D"],
+            "gradient_accumulation_steps": 1, "lr_scheduler": "constant_with_warmup", "lr_warmup_steps": 2,
+            "num_train_epochs": epochs, "save_per_epochs": 1}
+
+
+def _run(tmp, name, epochs, resume=0):
+    d = os.path.join(tmp, name) + os.sep
+    os.makedirs(d, exist_ok=True)
+    cfg = os.path.join(d, "cfg.json")
+    json.dump(_config(epochs), open(cfg, "w"))
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--synthetic", "12", "--config_file", cfg, "--log_dir", d,
+           "--ckpt_dir", d, "--batch_size", "4", "--max_seq_length", "64", "--dtype", "f32"]
+    if resume:
+        cmd += ["--resume_epoch", str(resume)]
+    subprocess.run(cmd, check=True, cwd=ROOT, timeout=600)
+    return d
+
+
+@pytest.mark.gpu
+def test_resume_continues_the_same_trajectory(dev, tmp_path):
+    straight = _run(str(tmp_path), "straight", 2)
+    part = _run(str(tmp_path), "part", 1)
+    # same directory: epoch 1's files are there; ask for 2 epochs and resume after the first
+    json.dump(_config(2), open(os.path.join(part, "cfg.json"), "w"))
+    _run(str(tmp_path), "part", 2, resume=1)
+    a = torch.load(os.path.join(straight, "ckpt_2.pt"), map_location="cpu")
+    b = torch.load(os.path.join(part, "ckpt_2.pt"), map_location="cpu")
+    assert list(a) == list(b) and any(k.startswith("unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q") for k in a)
+    # f32 run; only the atomics' summation order differs between processes, which Adam's normalised update turns into +-lr
+    # on parameters whose gradient is noise: compare the mean deviation with the mean distance travelled in epoch 2
+    first = torch.load(os.path.join(straight, "ckpt_1.pt"), map_location="cpu")
+    fl = [k for k in a if a[k].is_floating_point() and "proj_out" not in k and "inv_freq" not in k]
+    dev_ = sum(float((a[k].float() - b[k].float()).abs().sum()) for k in fl) / sum(a[k].numel() for k in fl)
+    moved = sum(float((a[k].float() - first[k].float()).abs().sum()) for k in fl) / sum(a[k].numel() for k in fl)
+    assert moved > 1e-5 and dev_ < 0.05 * moved, (dev_, moved)
+    oa = torch.load(os.path.join(straight, "optim_2.pt"), map_location="cpu")
+    ob = torch.load(os.path.join(part, "optim_2.pt"), map_location="cpu")
+    assert oa["step"] == ob["step"] == 6 and oa["opt_step"] == ob["opt_step"]
+    # without the optimizer state the second epoch would restart Adam's moments: make sure they were carried over
+    # (restarted moments would be ~half as large after 3 instead of 6 steps; run-to-run noise is a few per cent)
+    assert float((oa["exp_avg_sq"] - ob["exp_avg_sq"]).abs().sum()) <= 0.1 * float(oa["exp_avg_sq"].abs().sum())

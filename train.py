@@ -70,7 +70,21 @@ def main(args):
     st = model.store
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
     global_step = opt_step = 0
-    for epoch in range(config["num_train_epochs"]):
+    start_epoch = 0
+    if args.resume_epoch:
+        # the resume the reference never wrote (it only saves, train.py:139-144): model, Adam moments + step, LR-schedule
+        # position and the noise / timestep generator of this rank, from the files written at the end of that epoch
+        model.load_state_dict(torch.load(args.ckpt_dir + f"ckpt_{args.resume_epoch}.pt", map_location=dev))
+        opt = torch.load(args.ckpt_dir + f"optim_{args.resume_epoch}.pt", map_location=dev)
+        if opt["names"] != st.names:
+            raise RuntimeError("optimizer checkpoint does not match this model's parameter list")
+        st.adam_m = opt["exp_avg"].to(dev).clone(); st.adam_v = opt["exp_avg_sq"].to(dev).clone(); st.step_count = int(opt["step"])
+        opt_step, global_step = int(opt.get("opt_step", st.step_count)), int(opt.get("global_step", st.step_count * accum))
+        if "gen_state" in opt and rank < len(opt["gen_state"]):
+            gen.set_state(opt["gen_state"][rank].cpu())
+        start_epoch = args.resume_epoch
+        logging.info(f"resumed after epoch {start_epoch}: optimizer step {opt_step}")
+    for epoch in range(start_epoch, config["num_train_epochs"]):
         logging.info(f"Starting epoch {epoch}:")
         torch.manual_seed(epoch)                                            # same shuffle on every rank (accelerate C7)
         micro = 0
@@ -105,12 +119,17 @@ def main(args):
                         if writer is not None:
                             writer.add_scalar("Loss/train", train_loss, global_step)
                 loss_acc.zero_()
+        gen_states = [gen.get_state()]
         if world > 1:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, gen.get_state().cpu())
+            gen_states = gathered
             torch.distributed.barrier()
         if rank == 0 and epoch % config["save_per_epochs"] == 0:
             # same file names as the reference, which concatenates ckpt_dir and the name without a separator
             torch.save(model.state_dict(), args.ckpt_dir + f"ckpt_{epoch + 1}.pt")
-            torch.save({"step": st.step_count, "exp_avg": st.adam_m, "exp_avg_sq": st.adam_v, "names": st.names},
+            torch.save({"step": st.step_count, "exp_avg": st.adam_m, "exp_avg_sq": st.adam_v, "names": st.names,
+                        "opt_step": opt_step, "global_step": global_step, "gen_state": gen_states},
                        args.ckpt_dir + f"optim_{epoch + 1}.pt")
     if writer is not None:
         writer.flush(); writer.close()
@@ -129,6 +148,7 @@ def parse_args():
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic LJSpeech-shaped items instead of a tar")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--log_every", type=int, default=10)
+    p.add_argument("--resume_epoch", type=int, default=0, help="continue after this epoch from ckpt_dir's ckpt_N.pt / optim_N.pt")
     a = p.parse_args()
     if not a.synthetic and not a.data_file:
         p.error("--data_file is required (or --synthetic N)")
