@@ -150,6 +150,22 @@ def encode_bench(dev, prompts=32, seconds=12, iters=3):
             "weights": "seeded random (no checkpoint offline)"}
 
 
+def sample_bench(model, batch, wl, n_steps=10):
+    """Build-defined token generation stage: ancestral DDPM sampling with the training model (ms per reverse step)."""
+    from prompt_tts_amd import sampler
+    ids, mask = batch[3], batch[4]
+    gen = torch.Generator(device=ids.device); gen.manual_seed(11)
+    sampler.sample(model, ids, mask, wl["T"], 2, generator=gen); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sampler.sample(model, ids, mask, wl["T"], n_steps, generator=gen)
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / n_steps
+    toks = wl["B"] * wl["n_q"] * wl["T"]
+    return {"metric": "generated codec-tokens/sec (DDPM ancestral sampling, 1000 reverse steps)", "value": toks / (per * 1000),
+            "unit": "codec-tokens/s", "ms_per_reverse_step": per * 1e3, "prompts": wl["B"], "frames": wl["T"],
+            "audio_s_per_s_at_1000_steps": wl["B"] * wl["T"] / 75.0 / (per * 1000), "timed_steps": n_steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +303,8 @@ def main():
         out["decode"] = decode_bench(dev)
         note("encode leg (32 waveforms x 12 s)")
         out["encode"] = encode_bench(dev)
+        note("sampling leg (reverse diffusion with the training model)")
+        out["generate"] = sample_bench(model, batch, wl)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, wl, S)
     if rank == 0:

@@ -291,6 +291,10 @@ int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
  * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.
  * ---------------------------------------------------------------------------------------------- */
 /* codes[i] = clamp(rint((x[i] + 1) / 2 * (bins-1)), 0, bins-1): inverse of the collate normalisation (dataloader.py:64,143). */
+/* One ancestral DDPM step (the sampler the reference implies with its DDPMScheduler(1000), train.py:32-36, but never wrote):
+ * out = c_x0 * clamp((x - c_eps*eps) * c_inv, -clip, clip) + c_xt * x + sigma * z   (z may be NULL; clip <= 0: no clamp). */
+int pt_ddpm_step(const float* x, const float* eps, const float* z, float* out, int64_t n, float c_eps, float c_inv,
+                 float clip, float c_x0, float c_xt, float sigma, pt_stream stream);
 int pt_codes_from_continuous(const float* x, int64_t* codes, int64_t n, int64_t bins, pt_stream stream);
 /* Per row of logits[R][V] (RVQ-codebook logits head output): k == 1 greedy argmax (lowest index on ties); k > 1: softmax
  * over the k largest at `temperature`, inverse-CDF draw with the INJECTED uniform[row] in [0,1).  V <= 2048, k <= 64. */

@@ -99,6 +99,7 @@ SIGNATURES = {
                       _i32, _vp],
     "pt_pack_shadow": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pt_rvq_decode": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pt_ddpm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "pt_rvq_search": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
     "pt_rowconv": [C.POINTER(pt_rowconv_desc), _i32, _vp],
     "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],

@@ -43,6 +43,21 @@ __global__ __launch_bounds__(NT) void geglu_bwd_kernel(const T* __restrict__ dou
   }
 }
 
+// ---- DDPM ancestral step (diffusers DDPMScheduler.step, epsilon prediction, fixed_small variance, clip_sample) -----------
+// x_prev = c_x0 * clamp((x - c_eps * eps) * c_inv, -clip, clip) + c_xt * x + sigma * z      (all f32, n elements)
+__global__ __launch_bounds__(NT) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                       const float* __restrict__ z, float* __restrict__ out, int64_t n,
+                                                       float c_eps, float c_inv, float clip, float c_x0, float c_xt, float sigma) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const float xv = x[i];
+    float x0 = (xv - c_eps * eps[i]) * c_inv;
+    if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+    float r = c_x0 * x0 + c_xt * xv;
+    if (z) r += sigma * z[i];
+    out[i] = r;
+  }
+}
+
 // ---- flat unary/binary ------------------------------------------------------------------------------------
 template <typename T, int OP>   // 0 silu fwd (a=x) ; 1 silu bwd (a=dy, b=x) ; 2 add
 __global__ __launch_bounds__(NT) void flat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
@@ -262,6 +277,15 @@ __global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, 
     PT_LAUNCH_CHECK();                                   \
     return PT_OK;                                        \
   } while (0)
+
+extern "C" int pt_ddpm_step(const float* x, const float* eps, const float* z, float* out, int64_t n, float c_eps, float c_inv,
+                            float clip, float c_x0, float c_xt, float sigma, pt_stream stream) {
+  if (!x || !eps || !out || n <= 0) return PT_ERR_ARG;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, x, eps, z, out, n, c_eps, c_inv, clip,
+                     c_x0, c_xt, sigma);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
 
 extern "C" int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream) {
   if (M <= 0 || F <= 0 || F % 8 != 0) return PT_ERR_SHAPE;

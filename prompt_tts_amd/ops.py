@@ -244,6 +244,11 @@ def pack_shadow(p, shadow, seg_dev, n_seg):
           "pt_pack_shadow")
 
 
+def ddpm_step(x, eps, z, out, c_eps, c_inv, clip, c_x0, c_xt, sigma):
+    check(lib.pt_ddpm_step(_p(x), _p(eps), _p(z), _p(out), x.numel(), c_eps, c_inv, clip, c_x0, c_xt, sigma, _stream()),
+          "pt_ddpm_step")
+
+
 def codes_from_continuous(x, bins=1024):
     """(B, n_q, T) f32 in [-1, 1] -> int64 code indices (inverse of the collate normalisation)."""
     x = x.contiguous().float()
