@@ -91,6 +91,10 @@ typedef struct pt_gemm_desc {
   int32_t act;                   /* 0 none, 1 ELU(alpha=1) applied to what is stored in C         */
   int32_t act2;                  /* same for the optional second output                            */
   void* C2; int64_t ldc2;        /* optional second store of the same tile (e.g. raw + ELU), or NULL */
+  float* arow_sum;               /* PT_OUT_F32_ATOMIC only, or NULL: arow_sum[m] += alpha * sum_k VA(m,k) for m < arow_n -- the bias
+                                    gradient (column sums of dy) rides on the wgrad GEMM as one extra all-ones MFMA column, in
+                                    the workgroups of the first tile column; replicated destination like pt_colsum           */
+  int64_t arow_n; int64_t arow_stride; int32_t arow_rep; int32_t _pad2;
 } pt_gemm_desc;
 
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);

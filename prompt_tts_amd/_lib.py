@@ -29,7 +29,9 @@ class pt_gemm_desc(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("residual2", C.c_void_p), ("ldr2", C.c_int64),
                 ("conv_wgrad_cin", C.c_int32),
                 ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
-                ("C2", C.c_void_p), ("ldc2", C.c_int64)]
+                ("C2", C.c_void_p), ("ldc2", C.c_int64),
+                ("arow_sum", C.c_void_p), ("arow_n", C.c_int64), ("arow_stride", C.c_int64), ("arow_rep", C.c_int32),
+                ("_pad2", C.c_int32)]
 
 
 class pt_attn_desc(C.Structure):

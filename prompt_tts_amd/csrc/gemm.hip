@@ -49,6 +49,7 @@ struct GemmParams {
   int conv_wgrad_cin, conv_wgrad_cin_store;
   float alpha;
   int act, act2; char* C2; int64_t ldc2;
+  float* arow_sum; int64_t arow_n, arow_stride; int arow_rep;
   int tiles_m, tiles_n;
 };
 
@@ -379,6 +380,17 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // bias gradient on the wgrad GEMM: sum_k VA(m,k) as one extra MFMA column against an all-ones fragment, computed once per
+  // output row panel (first tile column, first wave column) -- replaces a separate column-sum pass over dy
+  const bool do_sum = ATOMIC && p.arow_sum != nullptr && tn == 0 && wn == 0;
+  f32x4_t accb[MI];
+  Frag<T> fones;
+  {
+    const float one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    frag_from_f32(fones, one8);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
   // One wave-instruction of global_load_lds writes 64 x 16 B = 1 KiB of LDS linearly (base + lane*16).  Chunk slot
   // q of a tile image therefore holds, for TileK, row q>>3 / data chunk (q&7)^(row&7); for TileT, k-row q/TCH /
@@ -465,6 +477,10 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
           if (ATOMIC) mma16(acc[i][j], fa[i], fb[j]);   // D[row = m][col = n]
           else        mma16(acc[i][j], fb[j], fa[i]);   // D[row = n][col = m]: 4 consecutive n per lane
         }
+      if (ATOMIC && do_sum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) mma16(accb[i], fa[i], fones);
+      }
     }
   };
   if (NSTAGE == 2) {
@@ -496,6 +512,16 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   }
 
   if (PT_GEMM_ABLATE == 6) return;      // probe: everything but the epilogue code
+  if (ATOMIC && do_sum && li == 0) {     // column 0 of the ones product: rows 4g + r of each 16-row block
+    float* dst = p.arow_sum + (int64_t)(blockIdx.x % p.arow_rep) * p.arow_stride;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * WM + 16 * i + 4 * g + r;
+        if (m < p.arow_n) unsafeAtomicAdd(dst + m, p.alpha * accb[i][r]);
+      }
+  }
   gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE);
 }
 
@@ -786,7 +812,8 @@ int launch_8p(GemmParams p, hipStream_t s) {
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
 int launch(const GemmParams& p, hipStream_t s) {
   constexpr int cls = ATOMIC ? 4 : (!TB ? (KA == 0 ? 0 : 2) : (KA == 0 ? 1 : 3));
-  const int tile = pick_tile(p, cls, sizeof(T) == 2);
+  int tile = pick_tile(p, cls, sizeof(T) == 2);
+  if (p.arow_sum && tile != 128) tile = 128;            // the fused bias gradient lives in the two-stage 128 x 128 kernel
   if constexpr (sizeof(T) == 2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB>(p, s); }
   switch (tile) {
     case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256>(p, s);
@@ -855,6 +882,8 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.conv_wgrad_cin_store = d->conv_wgrad_cin_store > 0 ? d->conv_wgrad_cin_store : d->conv_wgrad_cin;
   p.alpha = d->alpha;
   p.act = d->act; p.act2 = d->act2; p.C2 = reinterpret_cast<char*>(d->C2); p.ldc2 = d->ldc2;
+  p.arow_sum = d->arow_sum; p.arow_n = d->arow_n; p.arow_stride = d->arow_stride; p.arow_rep = d->arow_rep > 0 ? d->arow_rep : 1;
+  if (p.arow_sum && (d->out_kind != PT_OUT_F32_ATOMIC || d->arow_n <= 0 || d->arow_n > d->M || (p.arow_rep > 1 && d->arow_stride < d->arow_n))) return PT_ERR_ARG;
   p.tiles_m = p.tiles_n = 0;   // set per tile configuration in launch_bm
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);

@@ -274,13 +274,12 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
     K = x.shape[1]
     pt = ops.pt_dtype(x)
     def wgrad():
+        kw = {}
+        if gbias is not None:            # the bias gradient (column sums of dy) rides on the wgrad GEMM
+            (gb,), n_rep, rstride = _rep(gbias)
+            kw = dict(arow_sum=gb, arow_n=N, arow_rep=n_rep, arow_stride=rstride)
         ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
-                 out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype))
-        if gbias is not None:
-            for c0 in range(0, N, 8192):                 # the column-sum kernel keeps its columns in LDS
-                c1 = min(N, c0 + 8192)
-                (gb,), n_rep, rstride = _rep(gbias[c0:c1])
-                ops.colsum(dy[:, c0:c1], gb, M, c1 - c0, n_rep=n_rep, rep_stride=rstride)
+                 out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype), **kw)
     on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
@@ -330,12 +329,13 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
     padded = cin_store is not None and cin_store != cin
 
     def wgrad():
-        ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
-                 gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
-                 conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0)
+        kw = {}
         if gbias is not None:
             (gb,), n_rep, rstride = _rep(gbias)
-            ops.colsum(dy, gb, Mred, gbias.numel(), n_rep=n_rep, rep_stride=rstride)
+            kw = dict(arow_sum=gb, arow_n=gbias.numel(), arow_rep=n_rep, arow_stride=rstride)
+        ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
+                 gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
+                 conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0, **kw)
     on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None

@@ -67,7 +67,7 @@ def wflip(w3, cout, cin_pad, trans=True):
 
 def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bias=None, row_bias=None,
          row_bias_rows=0, row_bias_ld=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0,
-         act=0, out2=None, ldc2=0, act2=0):
+         act=0, out2=None, ldc2=0, act2=0, arow_sum=None, arow_n=0, arow_rep=1, arow_stride=0):
     d = L.pt_gemm_desc()
     d.M, d.N, d.K = M, N, K
     d.A, d.B = A, B
@@ -79,6 +79,7 @@ def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bi
     d.conv_wgrad_cin = conv_wgrad_cin; d.conv_wgrad_cin_store = conv_wgrad_cin_store
     d.alpha = alpha
     d.act = act; d.act2 = act2; d.C2 = _p(out2); d.ldc2 = ldc2
+    d.arow_sum = _p(arow_sum); d.arow_n = arow_n; d.arow_rep = arow_rep; d.arow_stride = arow_stride
     check(lib.pt_gemm(C.byref(d), dtype, _stream()), "pt_gemm")
 
 

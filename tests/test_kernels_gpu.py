@@ -81,6 +81,14 @@ def test_gemm_wgrad_tt_atomic(dev, dtype, split):
              out_kind=L.PT_OUT_F32_ATOMIC, split_k=split)
     ref = dyf.t() @ xf + 1.0
     assert relerr(dw, ref) < TOL[dtype]
+    # the bias gradient rides on the same GEMM (all-ones MFMA column): replicated destination, first 130 of 136 rows only
+    dw2 = torch.zeros(Nout, Kin, dtype=torch.float32, device=dev)
+    rep = torch.full((3, 192), 0.5, device=dev)
+    ops.gemm(Nout, Kin, Mred, ops.plain(dy, trans=True), ops.plain(x, trans=True), dw2, ops._DT[dtype],
+             out_kind=L.PT_OUT_F32_ATOMIC, split_k=split, arow_sum=rep[0], arow_n=130, arow_rep=3, arow_stride=192)
+    assert relerr(dw2, ref - 1.0) < TOL[dtype]
+    got = rep.sum(0) - 1.5
+    assert relerr(got[:130], dyf.sum(0)[:130]) < TOL[dtype] and float(got[130:].abs().max()) == 0.0
 
 
 def _tok(x):   # (B,C,N) -> token-major (B*N, C)
