@@ -372,7 +372,7 @@ class ZeroArena:
         self.off = 0
         self.dirty = False
         self.folds = []                  # (rep_off, rep_stride, dst data_ptr, n) not yet folded
-        self._seg_key = None; self._seg_dev = None
+        self._seg_cache = {}              # fold segment tables on the device, keyed by their contents (one per flush position)
 
     def reset(self):
         if self.folds:
@@ -411,15 +411,17 @@ class ZeroArena:
             return
         base = flat_g.data_ptr()
         key = tuple((ro, rs, (dp - base) // 4, n) for ro, rs, dp, n in self.folds)
-        if key != self._seg_key:
+        seg_dev = self._seg_cache.get(key)
+        if seg_dev is None:
             raw = (L.pt_fold_seg * len(key))()
             for i, (ro, rs, do, n) in enumerate(key):
                 if do < 0 or do + n > flat_g.numel():
                     raise RuntimeError("replicated destination is not a view of the flat gradient buffer")
                 raw[i].rep_off, raw[i].rep_stride, raw[i].dst_off, raw[i].n = ro, rs, do, n
-            self._seg_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(flat_g.device)
-            self._seg_key = key
-        ops.fold_replicas(self.buf, flat_g, self._seg_dev, len(key), N_REP, max(k[3] for k in key))
+            if len(self._seg_cache) > 64:
+                self._seg_cache.clear()
+            seg_dev = self._seg_cache[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(flat_g.device)
+        ops.fold_replicas(self.buf, flat_g, seg_dev, len(key), N_REP, max(k[3] for k in key))
         self.folds.clear()
 
 

@@ -24,6 +24,10 @@ class GradReducer:
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self._pending, self._pending_bytes, self._done, self._work = [], 0, [], []
         self.launched = []          # [(lo, hi)] in launch order (inspected by tests)
+        # called on the communication stream in front of every bucket: attach() makes that stream (not the compute stream)
+        # wait for the weight-gradient side stream and fold the replicated small gradients, so backward never stalls
+        self.pre_flush = None
+        self.joins_side_stream = False
 
     @property
     def grad_scale(self):
@@ -61,6 +65,8 @@ class GradReducer:
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
+                if self.pre_flush is not None:
+                    self.pre_flush()
                 for lo, hi in ranges:
                     dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
         else:
@@ -94,5 +100,13 @@ def attach(model, process_group=None, bucket_bytes=64 << 20):
     st = model.store
     r = GradReducer(st.flat_g, lambda m: st.span(list(m.parameters())) if any(True for _ in m.parameters()) else (0, 0),
                     process_group, bucket_bytes)
+    if r.cuda and __import__("os").environ.get("PT_DP_HOOK_JOIN", "0") != "1":
+        from . import engine as E
+
+        def pre_flush():                 # runs with the communication stream current
+            E.join_side_stream(st.device)
+            E.fold_grad_replicas(st.flat_g)
+        r.pre_flush = pre_flush
+        r.joins_side_stream = True
     model.grad_ready_hook = r.on_ready
     return r

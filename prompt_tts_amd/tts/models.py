@@ -198,10 +198,13 @@ class TTSSingleSpeaker(nn.Module):
         user_hook = self.grad_ready_hook
         hook = None
         if user_hook is not None:
-            def hook(module):                     # weight gradients are produced on the side stream: join it first
-                E.join_side_stream(st.device)
-                E.fold_grad_replicas(st.flat_g)
-                user_hook(module)
+            if getattr(getattr(user_hook, "__self__", None), "joins_side_stream", False):
+                hook = user_hook                  # the reducer orders its own stream after the wgrad stream: no stall here
+            else:
+                def hook(module):                 # weight gradients are produced on the side stream: join it first
+                    E.join_side_stream(st.device)
+                    E.fold_grad_replicas(st.flat_g)
+                    user_hook(module)
         dctx = self.unet.bwd(st, utape, dpred, hook)
         self.text_encoder.bwd(st, sv_text, dctx)
         if hook is not None:
