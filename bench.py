@@ -268,8 +268,10 @@ def main():
     note(f"timed {args.steps} steps: {wall / args.steps * 1e3:.1f} ms/step")
     if rank == 0 and world == 1:
         # per-symbol device times of ONE extra step (HIP events around every C-ABI call on the launch stream); the
-        # dominant symbol's average is what profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats) must agree with
-        kern = ops.profile_one_step(step)
+        # dominant symbol's average is what profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats) must agree with.
+        # "roofline" = that dominant kernel (per launch); "roofline_step" = the aggregate of all launches of one step
+        captured = []
+        kern = ops.profile_one_step(step, capture=captured)
         mf = {k: v for k, v in kern.items() if "tflops" in v and k.startswith("gemm<" + args.dtype)}
         # HBM-side bytes come from the committed rocprofv3 PMC passes of this same command (profiles/, see tools/rocprof_summary.py)
         pmc = None
@@ -289,13 +291,18 @@ def main():
             if pmc is not None and "atomic" in name:            # the wgrads run on the two-stage kernel only: one symbol
                 hit = [k for k in pmc["kernels"] if symbol in k["kernel"]]
                 traffic = hit[0]["bytes_per_launch"] if hit else None
-            out["roofline_kernel"] = {
+            out["roofline_step"] = out["roofline"]          # the aggregate MFMA roofline of the whole step stays available
+            out["roofline"] = {
                 "kernel": name, "symbol": symbol if "atomic" in name else symbol + " / gemm8p_kernel<...> (tile chosen per shape)",
                 "bound": "mfma", "calls_per_step": mf[name]["calls"], "avg_us": mf[name]["ms_avg"] * 1e3,
                 "algorithmic_gflop_per_launch": mf[name]["gflop_avg"], "achieved": mf[name]["tflops"], "peak": peak,
                 "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "traffic": traffic,
                 "share_of_step": mf[name]["ms_total"] / (step_s * 1e3),
                 "note": "averaged over all launches of one step, measured while the dgrad chain runs beside it on the main stream"}
+            calls, iso_us, iso_tf = ops.replay_gemms(captured, name)
+            out["roofline"]["isolated"] = {"calls": calls, "avg_us": iso_us, "achieved": iso_tf, "frac": iso_tf / peak,
+                                           "note": "the same launches of one step replayed back to back, alone on the chip"}
+            del captured
         if args.kernel_timing:
             out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_decode:

@@ -269,9 +269,10 @@ def sample_topk(logits, k=1, uniforms=None, temperature=1.0):
 
 # ---- per-symbol device timing (bench.py --kernel-timing): HIP events around every C-ABI call of one step ----------
 
-def profile_one_step(step_fn):
+def profile_one_step(step_fn, capture=None):
     """Run step_fn() once with every pt_* call bracketed by HIP events on the launch stream.
-    Returns {label: {calls, ms_total, ms_avg, tflops (GEMM/attention), gflop_avg}} sorted by time."""
+    Returns {label: {calls, ms_total, ms_avg, tflops (GEMM/attention), gflop_avg}} sorted by time.
+    capture: a list that receives (label, descriptor copy, dtype, flops) of every pt_gemm call (replayed by replay_gemms)."""
     recs = []
     originals = {}
 
@@ -289,6 +290,9 @@ def profile_one_step(step_fn):
     def wrap(name, fn):
         def inner(*args):
             lab, fl = label_and_flops(name, args)
+            if capture is not None and name == "pt_gemm":
+                d = args[0]._obj
+                capture.append((lab, type(d).from_buffer_copy(d), args[1], fl))
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*args)
@@ -317,3 +321,25 @@ def profile_one_step(step_fn):
             out[lab]["tflops"] = round(a["flops"] / (a["ms_total"] * 1e-3) / 1e12, 1)
             out[lab]["gflop_avg"] = round(a["flops"] / a["calls"] / 1e9, 2)
     return out
+
+
+def replay_gemms(captured, label, rounds=3):
+    """Re-issue the captured pt_gemm launches with `label` back to back on the current stream (alone on the chip) and
+    return (calls, average microseconds, TFLOP/s).  The operand buffers of the captured step may have been recycled by the
+    caching allocator: they are still mapped, their contents are irrelevant to the timing, and the outputs (gradient buffers,
+    scratch) are overwritten by the next real step anyway."""
+    sel = [(d, dt, fl) for lab, d, dt, fl in captured if lab == label]
+    if not sel:
+        return 0, 0.0, 0.0
+    st = _stream()
+    for d, dt, _ in sel:
+        check(lib.pt_gemm(C.byref(d), dt, st), "pt_gemm")
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        for d, dt, _ in sel:
+            lib.pt_gemm(C.byref(d), dt, st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (rounds * len(sel))
+    return len(sel), us, sum(f for _, _, f in sel) / len(sel) / us / 1e6
