@@ -85,8 +85,42 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.pt_gemm(ctypes.byref(d), 1, None) == -1
     assert _lib.lib.pt_gemm(ctypes.byref(d), 7, None) == -2
     assert _lib.lib.pt_attn_fwd(None, 1, None) == -5
-    for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg, _lib.pt_rowconv_desc, _lib.pt_lstm2_desc)):
+    for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg, _lib.pt_rowconv_desc,
+                            _lib.pt_lstm2_desc, _lib.pt_fold_seg)):
         assert _lib.lib.pt_struct_size(i) == ctypes.sizeof(st)          # the ctypes mirror matches the C layout
+
+
+def test_cabi_refuses_bad_arguments_with_a_status_never_a_launch():
+    """Every entry point validates before it touches HIP: misuse is a negative status, not an exception or a fault."""
+    from prompt_tts_amd import _lib
+    lib, L = _lib.lib, _lib
+    OKP = 0x10000                                            # a 16-byte aligned non-null "pointer" that is never dereferenced
+    d = L.pt_gemm_desc(); d.M, d.N, d.K = 128, 128, 64
+    d.A.p, d.A.ld, d.B.p, d.B.ld, d.C, d.ldc, d.split_k, d.alpha = OKP, 64, OKP, 64, OKP, 128, 1, 1.0
+    bad = L.pt_gemm_desc.from_buffer_copy(d); bad.A.p = OKP + 2
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16, None) == -4                    # misaligned operand
+    bad = L.pt_gemm_desc.from_buffer_copy(d); bad.split_k = 4
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16, None) == -5                    # split-K needs the atomic output kind
+    bad = L.pt_gemm_desc.from_buffer_copy(d); bad.arow_sum = OKP; bad.arow_n = 64
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16, None) == -5                    # fused bias gradient only on the wgrad
+    bad = L.pt_gemm_desc.from_buffer_copy(d); bad.A.kind = L.PT_V_CONV; bad.A.taps = 3; bad.A.cin = 4
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16, None) == -1                    # conv channels must be whole 16-byte chunks
+    bad = L.pt_gemm_desc.from_buffer_copy(d); bad.A.kind = L.PT_V_CONV; bad.A.taps = 4; bad.A.cin = 64; bad.A.n_out = 8; bad.A.n_in = 16
+    bad.A.rowmap = L.PT_MAP_STRIDED_REFLECT; bad.A.stride = 0
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16, None) == -1                    # strided map without a stride
+    assert lib.pt_layernorm_fwd(OKP, OKP, OKP, OKP, OKP, OKP, 16, 12, 1e-5, L.PT_BF16, None) == -1       # C % 8
+    assert lib.pt_layernorm_bwd(OKP, OKP, OKP, OKP, OKP, None, OKP, OKP, OKP, 16, 64, 0, 0, L.PT_BF16, None) == -5   # n_rep < 1
+    assert lib.pt_colsum(OKP, 64, OKP, 0, 16, 64, 16, 4, 0, L.PT_BF16, None) == -5                        # replicas need a stride
+    assert lib.pt_groupnorm_fwd(OKP, None, OKP, OKP, OKP, OKP, OKP, 2, 16, 64, 0, 32, -1.0, 1, L.PT_BF16, None) == -1   # eps < 0
+    assert lib.pt_rvq_search(OKP, OKP, OKP, OKP, 2, 8, 10, 8, 1024, 128, None) == -1                      # stage index out of range
+    assert lib.pt_ddpm_step(None, OKP, None, OKP, 10, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, None) == -5
+    assert lib.pt_fold_replicas(OKP, OKP, None, 3, 16, 64, None) == -5
+    r = L.pt_rowconv_desc(); r.B, r.n_rows, r.N, r.cin, r.taps, r.rowmap = 2, 16, 96, 32, 3, L.PT_MAP_CAUSAL_REFLECT
+    assert lib.pt_rowconv(ctypes.byref(r), L.PT_BF16, None) == -1                   # more than 64 output channels
+    l = L.pt_lstm2_desc(); l.B, l.T, l.H = 4, 10, 300
+    assert lib.pt_lstm2_forward(ctypes.byref(l), L.PT_BF16, None) == -1             # hidden size must be a multiple of 256
+    assert lib.pt_geglu_fwd(OKP, OKP, 16, 12, L.PT_BF16, None) == -1
+    assert lib.pt_geglu_fwd(OKP, OKP, 16, 16, 9, None) == -2                        # unknown dtype
 
 
 def test_product_never_imports_oracle_or_reference():
