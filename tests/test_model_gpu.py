@@ -166,3 +166,26 @@ def test_grad_accumulation_and_zero_grad(dev):
     with torch.no_grad():
         out2 = m(xt, t, ids, mask).sample                # shadow weights were refreshed automatically
     assert relerr(out2, z["out"]) > 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_full_size_config_b_batch_items_are_independent(dev, dtype, tol):
+    """BASELINE configs[1] at its full model size (163 M parameters, T_code 1024, T_text 256): a size-independent property
+    of the denoiser -- every batch item is processed independently (GroupNorm, attention and all GEMM row tiles are per item),
+    so a batch of 3 equals its items run one at a time; two runs of the same batch agree (bitwise in bf16)."""
+    import bench
+    from oracle.init import deterministic_init_
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    wl = bench.WORKLOADS["B"]
+    cfg = bench.make_config(wl["d"], wl["L"], wl["text_layers"], wl["n_q"], wl["T"], 256)
+    m = deterministic_init_(TTSSingleSpeaker(cfg, dtype=dtype), 11).to(dev)
+    x0, noise, t, ids, mask = [v.to(dev) for v in bench.synthetic_batch(3, wl["n_q"], wl["T"], 256, 21)]
+    with torch.no_grad():
+        full = m(noise, t, ids, mask).sample
+        again = m(noise, t, ids, mask).sample
+        assert full.shape == (3, wl["n_q"], wl["T"]) and bool(torch.isfinite(full).all())
+        # bf16: the one-pass GroupNorm reduces in a fixed order -> bitwise repeatable; f32: its statistics are f32 atomics
+        assert torch.equal(full, again) if dtype == torch.bfloat16 else relerr(again, full) < tol
+        for b in range(3):
+            one = m(noise[b:b + 1], t[b:b + 1], ids[b:b + 1], mask[b:b + 1]).sample
+            assert relerr(one, full[b:b + 1]) < tol, b
