@@ -98,6 +98,116 @@ class SingleSpeakerDataset(Dataset):
         return self.item_list[idx]
 
 
+class LazySingleSpeakerDataset(Dataset):
+    """Same items as SingleSpeakerDataset without holding the tar in RAM: one pass over the tar HEADERS builds
+    an index (member name -> data offset, size); __getitem__ seeks and reads only that utterance's members.  Random access
+    (shuffling) stays cheap because tar data is stored verbatim; every DataLoader worker opens its own file handle.
+    Tars written by generate_code.py / encode_codec.py keep all texts at the END of the archive, so a sequential stream would
+    have to buffer everything anyway: an offset index is the streaming form that fits this layout."""
+
+    def __init__(self, data_path, text_to_ids=None):
+        super().__init__()
+        self.data_path, self.text_to_ids = data_path, text_to_ids
+        self._fh = None
+        with tarfile.open(data_path, "r:") as tf:                       # uncompressed tar: offsets address the file itself
+            self.index = {m.name: (m.offset_data, m.size) for m in tf.getmembers() if m.isfile()}
+        self.stems = sorted(n[:-4] for n in self.index if n.endswith(".npy") and not n.endswith(".cmu.npy"))
+        for stem in self.stems:
+            for suffix in (".txt", ".len.txt"):
+                if stem + suffix not in self.index:
+                    raise KeyError(f"{stem}{suffix} missing from {data_path}")
+            if stem + ".cmu.npy" not in self.index and text_to_ids is None:
+                raise NotImplementedError(
+                    "the CMUdict text front-end is outside this build's scope: pass text_to_ids=... "
+                    "(e.g. the reference's text_to_sequence) or ship <utt>.cmu.npy phoneme ids in the tar")
+
+    def _read(self, name):
+        if self._fh is None:                                            # one handle per process (DataLoader workers fork)
+            self._fh = open(self.data_path, "rb")
+        off, size = self.index[name]
+        self._fh.seek(off)
+        return self._fh.read(size)
+
+    def __getstate__(self):
+        st = dict(self.__dict__); st["_fh"] = None
+        return st
+
+    def __len__(self):
+        return len(self.stems)
+
+    def __getitem__(self, idx):
+        stem = self.stems[idx]
+        code = np.load(io.BytesIO(self._read(stem + ".npy")))
+        text = self._read(stem + ".txt").decode()
+        has_norm = stem + ".normalized.txt" in self.index
+        text_norm = self._read(stem + ".normalized.txt").decode() if has_norm else text
+        if stem + ".cmu.npy" in self.index:
+            ids = np.load(io.BytesIO(self._read(stem + ".cmu.npy"))).tolist()
+        else:
+            ids = list(self.text_to_ids(text_norm))
+        item = {"code": code / 1023, "text": text, "cmu_sequence": intersperse(ids, BLANK_ID),
+                "code_length": float(self._read(stem + ".len.txt").decode())}
+        if has_norm:
+            item["text_norm"] = text_norm
+        return item
+
+
+class DeviceFeeder:
+    """Keeps the GPU fed: a background thread pulls collated batches, pins their tensors and copies them to `device` on its
+    own stream (`depth` batches ahead); the consumer gets dictionaries whose tensors are already resident and ordered after
+    the copy on the current stream.  The reference moves each batch synchronously inside the step loop (train.py:86-90)."""
+
+    def __init__(self, loader, device, depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), depth
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stream = torch.cuda.Stream(device=self.device)
+        stop = threading.Event()
+
+        def work():
+            try:
+                for batch in self.loader:
+                    if stop.is_set():
+                        return
+                    out = {}
+                    with torch.cuda.stream(stream):
+                        for k, v in batch.items():
+                            out[k] = v.pin_memory().to(self.device, non_blocking=True) if torch.is_tensor(v) else v
+                        ev = torch.cuda.Event(); ev.record(stream)
+                    q.put((out, ev))
+                q.put(None)
+            except BaseException as e:                                   # surface loader errors in the consumer
+                q.put(e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in batch.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(torch.cuda.current_stream(self.device))
+                yield batch
+        finally:
+            stop.set()
+            while th.is_alive():                                         # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+
 class SyntheticDataset(Dataset):
     """LJSpeech-shaped synthetic items: codes U{0..1023}, phoneme ids U{1..147} blank-interspersed."""
 
@@ -117,6 +227,11 @@ class SyntheticDataset(Dataset):
         return self.item_list[idx]
 
 
-def create_dataloader(data_file, batch_size, max_seq_length, shuffle=False, text_to_ids=None, dataset=None):
-    dataset = dataset if dataset is not None else SingleSpeakerDataset(data_file, text_to_ids)
-    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=TTS_SingleSpkr_Collate_Fn(max_seq_length))
+def create_dataloader(data_file, batch_size, max_seq_length, shuffle=False, text_to_ids=None, dataset=None, lazy=False,
+                      num_workers=0):
+    """Reference signature first (dataloader.py:191-198); `lazy=True` reads utterances on demand from an offset index instead of
+    loading the whole tar, `num_workers` collates in background processes."""
+    if dataset is None:
+        dataset = (LazySingleSpeakerDataset if lazy else SingleSpeakerDataset)(data_file, text_to_ids)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=TTS_SingleSpkr_Collate_Fn(max_seq_length),
+                      num_workers=num_workers, persistent_workers=num_workers > 0)

@@ -65,6 +65,55 @@ def test_dataset_from_tar_and_loader(tmp_path):
     assert b["cmu_sequence"][0][0] == 148 and float(b["code"].abs().max()) <= 1.0
 
 
+def _ljs_like_tar(path, n=7, with_cmu=True):
+    """A tar laid out like generate_code.py / encode_codec.py write it: codes + lengths first, every text at the END."""
+    import io
+    import tarfile
+    rng = np.random.default_rng(5)
+    with tarfile.open(path, "w") as tf:
+        def add(name, data):
+            ti = tarfile.TarInfo(name); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+        for i in range(n):
+            buf = io.BytesIO(); np.save(buf, rng.integers(0, 1024, (4, 30 + i))); add(f"LJ{i:03d}.npy", buf.getvalue())
+            add(f"LJ{i:03d}.len.txt", str(float(30 + i)).encode())
+            if with_cmu:
+                buf = io.BytesIO(); np.save(buf, rng.integers(1, 148, 5 + i)); add(f"LJ{i:03d}.cmu.npy", buf.getvalue())
+        for i in range(n):
+            add(f"LJ{i:03d}.txt", f"utterance number {i}".encode())
+            add(f"LJ{i:03d}.normalized.txt", f"utterance number {i} normalised".encode())     # all or none, as the reference needs
+
+
+def test_lazy_tar_dataset_equals_in_ram_dataset(tmp_path):
+    """the offset-indexed dataset yields exactly the items of the whole-tar-in-RAM one, also through worker
+    processes and a shuffled loader."""
+    from prompt_tts_amd.tts.dataloader import LazySingleSpeakerDataset, SingleSpeakerDataset, create_dataloader
+    path = str(tmp_path / "ljs.tar")
+    _ljs_like_tar(path)
+    ram, lazy = SingleSpeakerDataset(path), LazySingleSpeakerDataset(path)
+    assert len(ram) == len(lazy) == 7
+    for i in (3, 0, 6, 1, 5, 2, 4):                                # random access order
+        a, b = ram[i], lazy[i]
+        assert a.keys() == b.keys() and a["text"] == b["text"] and a["cmu_sequence"] == b["cmu_sequence"]
+        assert a["code_length"] == b["code_length"] and np.array_equal(a["code"], b["code"])
+        assert a.get("text_norm") == b.get("text_norm")
+    with pytest.raises(NotImplementedError):
+        bare = str(tmp_path / "bare.tar"); _ljs_like_tar(bare, with_cmu=False); LazySingleSpeakerDataset(bare)
+
+    class FixedT(torch.utils.data.Dataset):                          # codes of one length, as the 12 s windows of the reference
+        def __init__(self, ds): self.ds = ds
+        def __len__(self): return len(self.ds)
+        def __getitem__(self, i):
+            it = dict(self.ds[i]); it["code"] = it["code"][:, :30]; return it
+    ref = [b for b in create_dataloader(None, 3, 16, dataset=FixedT(ram))]
+    for workers in (0, 2):
+        got = [b for b in create_dataloader(None, 3, 16, dataset=FixedT(lazy), num_workers=workers)]
+        assert len(got) == len(ref) == 3
+        for x, y in zip(ref, got):
+            assert torch.equal(x["code"], y["code"]) and torch.equal(x["cmu_sequence_id"], y["cmu_sequence_id"])
+            assert torch.equal(x["attention_mask"], y["attention_mask"]) and x["text"] == y["text"]
+    assert len(create_dataloader(path, 2, 16, lazy=True).dataset) == 7
+
+
 def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "prompt_tts_hip.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(pt_\w+)\s*\(", hdr, flags=re.M))

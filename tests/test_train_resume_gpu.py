@@ -56,3 +56,29 @@ def test_resume_continues_the_same_trajectory(dev, tmp_path):
     # without the optimizer state the second epoch would restart Adam's moments: make sure they were carried over
     # (restarted moments would be ~half as large after 3 instead of 6 steps; run-to-run noise is a few per cent)
     assert float((oa["exp_avg_sq"] - ob["exp_avg_sq"]).abs().sum()) <= 0.1 * float(oa["exp_avg_sq"].abs().sum())
+
+
+@pytest.mark.gpu
+def test_device_feeder_delivers_the_same_batches_in_order(dev):
+    """The prefetching feeder changes WHERE the copies happen, not what arrives (and surfaces loader errors)."""
+    from prompt_tts_amd.tts.dataloader import DeviceFeeder, SyntheticDataset, create_dataloader
+    ds = SyntheticDataset(10, 4, 32, 64)
+    ref = list(create_dataloader(None, 3, 64, dataset=ds))
+    got = list(DeviceFeeder(create_dataloader(None, 3, 64, dataset=ds), dev, depth=2))
+    assert len(got) == len(ref) == 4
+    for a, b in zip(ref, got):
+        assert b["code"].device.type == "cuda" and b["attention_mask"].device.type == "cuda"
+        assert torch.equal(a["code"], b["code"].cpu()) and torch.equal(a["cmu_sequence_id"], b["cmu_sequence_id"].cpu())
+        assert a["text"] == b["text"] and a["cmu_sequence"] == b["cmu_sequence"]
+
+    class Boom:
+        def __iter__(self):
+            yield ref[0]
+            raise ValueError("broken shard")
+
+        def __len__(self):
+            return 2
+    it = iter(DeviceFeeder(Boom(), dev))
+    next(it)
+    with pytest.raises(ValueError, match="broken shard"):
+        next(it)

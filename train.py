@@ -20,12 +20,25 @@ import os
 import torch
 
 from prompt_tts_amd import parallel
-from prompt_tts_amd.tts.dataloader import SyntheticDataset, create_dataloader
+from prompt_tts_amd.tts.dataloader import DeviceFeeder, SyntheticDataset, create_dataloader
 from prompt_tts_amd.tts.models import TTSSingleSpeaker
 
 logging.basicConfig(format="%(asctime)s - %(levelname)s: %(message)s", level=logging.INFO, datefmt="%I:%M:%S")
 
 ADAMW = dict(lr=1e-5, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)      # hard-coded in the reference (train.py:41-47)
+
+
+class _Sized:
+    """An iterable with a known length (the rank's share of the batches)."""
+
+    def __init__(self, it, n):
+        self.it, self.n = it, n
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def __len__(self):
+        return self.n
 
 
 def lr_lambda(name, num_warmup_steps, num_training_steps):
@@ -62,7 +75,8 @@ def main(args):
     model = TTSSingleSpeaker(config, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
     reducer = parallel.attach(model) if world > 1 else None
     ds = SyntheticDataset(args.synthetic, config["in_channels"], config["sample_size"], args.max_seq_length) if args.synthetic else None
-    dataloader = create_dataloader(args.data_file, args.batch_size, args.max_seq_length, shuffle=True, dataset=ds)
+    dataloader = create_dataloader(args.data_file, args.batch_size, args.max_seq_length, shuffle=True, dataset=ds,
+                                   lazy=args.lazy_tar, num_workers=args.num_workers)
     accum = config["gradient_accumulation_steps"]
     steps_per_epoch = math.ceil(math.ceil(len(dataloader) / world) / accum)
     max_train_steps = config["num_train_epochs"] * steps_per_epoch
@@ -89,9 +103,9 @@ def main(args):
         torch.manual_seed(epoch)                                            # same shuffle on every rank (accelerate C7)
         micro = 0
         loss_acc = torch.zeros(1, device=dev)
-        for bi, batch in enumerate(dataloader):
-            if bi % world != rank:                                          # BatchSamplerShard round-robin
-                continue
+        # BatchSamplerShard round-robin over batches; this rank's batches are pinned and copied ahead of the step loop
+        mine = (b for bi, b in enumerate(dataloader) if bi % world == rank)
+        for batch in (DeviceFeeder(_Sized(mine, math.ceil(len(dataloader) / world)), dev) if args.prefetch else mine):
             codes = batch["code"].to(dev)
             ids = batch["cmu_sequence_id"].to(dev); mask = batch["attention_mask"].to(dev)
             noise = torch.randn(codes.shape, device=dev, generator=gen)
@@ -148,6 +162,9 @@ def parse_args():
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic LJSpeech-shaped items instead of a tar")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--log_every", type=int, default=10)
+    p.add_argument("--lazy_tar", action="store_true", help="read utterances on demand from an offset index instead of loading the tar")
+    p.add_argument("--num_workers", type=int, default=0, help="DataLoader worker processes (collate off the step loop)")
+    p.add_argument("--prefetch", type=int, default=1, help="1: pin + copy batches to the GPU two steps ahead (DeviceFeeder)")
     p.add_argument("--resume_epoch", type=int, default=0, help="continue after this epoch from ckpt_dir's ckpt_N.pt / optim_N.pt")
     a = p.parse_args()
     if not a.synthetic and not a.data_file:
