@@ -722,6 +722,13 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
 #undef P8_VMCNT
   if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align: every wave has finished its LDS reads past this point
   __builtin_amdgcn_s_barrier();
+  if (PT_GEMM_ABLATE == 6) {              // probe: everything but the epilogue (accumulators kept live)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * SCRATCH_PER_WAVE);
 }
 
