@@ -37,7 +37,8 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
   using Cfg = AttnCfg<T, D>;
   constexpr int KS = Cfg::KS, DT = Cfg::DT, COLS = Cfg::COLS;
-  constexpr int IMG = 32 * Cfg::ROWB;
+  constexpr int QT = 64;                          // queries per staged tile: two 32-query compute blocks per barrier
+  constexpr int IMG = QT * Cfg::ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q image | dO image]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
 
   // causal: queries before this workgroup's first key see none of its keys
   const int qstart = p.causal ? (kblk / 32) * 32 : 0;
-  const int nsteps = (p.Nq - qstart + 31) / 32;
+  const int nsteps = (p.Nq - qstart + QT - 1) / QT;
 
-  TileStage<T, D, 32> sq, sdo;
+  TileStage<T, D, QT> sq, sdo;
   if (nsteps > 0) {
     sq.load(Q, p.ldq, qstart, p.Nq, tid); sdo.load(DO, p.lddo, qstart, p.Nq, tid);
     sq.store(smem, tid); sdo.store(smem + IMG, tid);
@@ -84,11 +85,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
 
   int cur = 0;
   for (int st = 0; st < nsteps; ++st) {
-    const int qs = qstart + st * 32;
+    const int qs0 = qstart + st * QT;
     const bool more = st + 1 < nsteps;
-    if (more) { sq.load(Q, p.ldq, qs + 32, p.Nq, tid); sdo.load(DO, p.lddo, qs + 32, p.Nq, tid); }
+    if (more) { sq.load(Q, p.ldq, qs0 + QT, p.Nq, tid); sdo.load(DO, p.lddo, qs0 + QT, p.Nq, tid); }
     const char* qimg = smem + cur * 2 * IMG;
     const char* doimg = qimg + IMG;
+#pragma unroll
+    for (int hf = 0; hf < QT / 32; ++hf) {
+    const int qs = qs0 + 32 * hf, ro = 32 * hf;       // this block's first query / its row offset inside the images
+    if (qs >= p.Nq) break;
 
     f32x4_t s[2][2], dp[2][2];     // [q tile][key tile]; lane: key = lane&15, q = 4g + r
 #pragma unroll
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         Frag<T> a, d;
-        frag_load_n<COLS>(a, qimg, 16 * qt + li, ks * 32 + 8 * g);
-        frag_load_n<COLS>(d, doimg, 16 * qt + li, ks * 32 + 8 * g);
+        frag_load_n<COLS>(a, qimg, ro + 16 * qt + li, ks * 32 + 8 * g);
+        frag_load_n<COLS>(d, doimg, ro + 16 * qt + li, ks * 32 + 8 * g);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { mma16(s[qt][kt], a, fk[kt][ks]); mma16(dp[qt][kt], d, fv[kt][ks]); }
       }
@@ -148,11 +153,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       Frag<T> fdoT, fqT;
-      frag_load_t<COLS>(fdoT, doimg, 16 * dt, 4 * g, 16 + 4 * g, lane);
-      frag_load_t<COLS>(fqT, qimg, 16 * dt, 4 * g, 16 + 4 * g, lane);
+      frag_load_t<COLS>(fdoT, doimg, 16 * dt, ro + 4 * g, ro + 16 + 4 * g, lane);
+      frag_load_t<COLS>(fqT, qimg, 16 * dt, ro + 4 * g, ro + 16 + 4 * g, lane);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) { mma16(dv[dt][kt], fdoT, fp[kt]); mma16(dk[dt][kt], fqT, fds[kt]); }
     }
+    }   // hf
     if (more) { sq.store(smem + (cur ^ 1) * 2 * IMG, tid); sdo.store(smem + (cur ^ 1) * 2 * IMG + IMG, tid); }
     __syncthreads();
     cur ^= 1;
@@ -308,7 +314,7 @@ template <typename K> int set_lds(K kernel, size_t lds, bool& done) {
 template <typename T, int D> int launch_bwd(const AttnParams& p, hipStream_t s) {
   using Cfg = AttnCfg<T, D>;
   static bool a1 = false, a2 = false;
-  const size_t lds_kv = 2 * 2 * 32 * (size_t)Cfg::ROWB, lds_q = 2 * 2 * 64 * (size_t)Cfg::ROWB;
+  const size_t lds_kv = 2 * 2 * 64 * (size_t)Cfg::ROWB, lds_q = 2 * 2 * 64 * (size_t)Cfg::ROWB;
   int st;
   if ((st = set_lds(&attn_bwd_kv_kernel<T, D>, lds_kv, a1))) return st;
   if ((st = set_lds(&attn_bwd_q_kernel<T, D>, lds_q, a2))) return st;
