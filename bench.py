@@ -128,9 +128,33 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
     ms = e0.elapsed_time(e1) / iters
     audio_s = prompts * T / 75.0
     flops = 2 * 19863552 * prompts * T                     # 19.86 M MAC per frame
+    # token stage of configs[3] (build-defined ops, SURVEY 8a'): RVQ-codebook logits head Linear(d -> n_q * 1024) on (B, T, d)
+    # hidden states, then greedy / top-k = 32 sampling per (prompt, codebook, frame) with injected uniforms
+    from prompt_tts_amd import engine as E, ops
+    g = torch.Generator().manual_seed(8)
+    d_model, n_q, bins = 512, 8, 1024
+    hidden = (torch.randn(prompts * T, d_model, generator=g) * 0.5).to(dev, dtype)
+    w_head = (torch.randn(n_q * bins, d_model, generator=g) * d_model ** -0.5).to(dev, dtype)
+    uniforms = torch.rand(prompts * T * n_q, generator=g).to(dev)
+
+    def token_stage(k):
+        logits = E.linear_fwd(hidden, w_head).view(prompts * T * n_q, bins)
+        idx = ops.sample_topk(logits, k=k, uniforms=uniforms if k > 1 else None)
+        return idx.view(prompts, T, n_q).permute(0, 2, 1).contiguous()
+    stage_ms = {}
+    for k in (1, 32):
+        token_stage(k); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            sampled = token_stage(k)
+        e1.record(); torch.cuda.synchronize()
+        stage_ms[k] = e0.elapsed_time(e1) / iters
+    assert sampled.shape == codes.shape and int(sampled.min()) >= 0 and int(sampled.max()) < bins
     return {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
             "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
             "lstm_steps_per_s": 2 * T / (ms * 1e-3), "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+            "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
+            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
             "weights": "seeded random (no checkpoint offline)"}
 
 
