@@ -57,26 +57,29 @@ def decode(encoded_frames: torch.Tensor):
     return model.decode(encoded_frames)
 
 
-def main(args):
-    codec_matrix = np.load(args.npy_path)
-    encoded_frames = torch.tensor(codec_matrix)
-    if len(codec_matrix.shape) != 3:
-        encoded_frames = encoded_frames.unsqueeze(0)
-    load_decoder(args.weights, torch.float32 if args.dtype == "f32" else torch.bfloat16)
-    with torch.no_grad():
-        wav_dec = decode(encoded_frames)
+def write_wav(path, wav, sample_rate=EncodecDecoder.sample_rate):
+    """(1, n) or (n,) float waveform in [-1, 1] -> 16-bit PCM file (what soundfile writes by default in the reference)."""
     from scipy.io import wavfile
-    pcm = (wav_dec[0][0].clamp(-1, 1).cpu().numpy() * 32767.0).astype(np.int16)      # soundfile's default PCM_16
-    wavfile.write(args.npy_path.replace(".npy", ".wav"), EncodecDecoder.sample_rate, pcm)
+    mono = wav.reshape(-1).clamp(-1, 1).cpu().numpy()
+    wavfile.write(path, sample_rate, (mono * 32767.0).astype(np.int16))
 
 
-def parse_args():
-    parser = ArgumentParser(description="Test converting codec codes back to waveform.")
-    parser.add_argument("--npy_path", required=True, help="Path to codec codes matrix.")
-    parser.add_argument("--weights", default=None, help="encodec state_dict (.pt); random decoder if omitted")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    return parser.parse_args()
+def run_cli(npy_path, weights=None, dtype="bf16"):
+    """`--npy_path x.npy` -> x.wav (first item of the batch), as the reference's command line does."""
+    codes = torch.from_numpy(np.load(npy_path))
+    if codes.dim() == 2:                          # a single utterance saved as [N_q, T]
+        codes = codes[None]
+    load_decoder(weights, {"f32": torch.float32, "bf16": torch.bfloat16}[dtype])
+    wav = decode(codes)
+    out_path = npy_path[:-4] + ".wav" if npy_path.endswith(".npy") else npy_path + ".wav"
+    write_wav(out_path, wav[0])
+    return out_path
 
 
 if __name__ == "__main__":
-    main(parse_args())
+    cli = ArgumentParser(description="Codec codes (.npy, [N_q, T] or [B, N_q, T]) -> 24 kHz waveform next to the input file.")
+    cli.add_argument("--npy_path", required=True, help="codec code matrix written by the data preparation")
+    cli.add_argument("--weights", default=None, help="encodec state_dict (.pt); a seeded random decoder if omitted")
+    cli.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ns = cli.parse_args()
+    print(run_cli(ns.npy_path, ns.weights, ns.dtype))

@@ -13,8 +13,6 @@ import io
 import tarfile
 import wave
 from argparse import ArgumentParser
-from os.path import abspath
-from tempfile import TemporaryDirectory
 
 import numpy as np
 import torch
@@ -98,43 +96,38 @@ def generate(batch):
     return model.encode(wav).cpu().numpy()
 
 
+def _add_bytes(tar, name, payload):
+    info = tarfile.TarInfo(name)
+    info.size = len(payload)
+    tar.addfile(info, io.BytesIO(payload))
+
+
 def main(input_file, batch_size, max_duration):
-    output_file = input_file.replace(".tar", "_processed.tar")
-    tf = tarfile.open(input_file, "r")
-    members = tf.getmembers()
-    output_tf = tarfile.open(output_file, "w")
-    for batch in create_batch(members, tf, batch_size, max_duration):
-        codes = generate(batch[0])
-        with TemporaryDirectory() as dirname:
-            for i, code in enumerate(codes):
-                np_file = batch[1][i].replace(".wav", ".npy").split('/')[-1]
-                np.save(abspath(f"{dirname}/{np_file}"), code)
-                output_tf.add(abspath(f"{dirname}/{np_file}"), arcname=np_file)
-                len_file = np_file.replace(".npy", ".len.txt")
-                with open(abspath(f"{dirname}/{len_file}"), "w") as f:
-                    f.write(str(batch[2][i]))
-                output_tf.add(abspath(f"{dirname}/{len_file}"), arcname=len_file)
-    with TemporaryDirectory() as dirname:                         # text members travel unchanged
-        for member in members:
-            if ".txt" in member.name:
-                tf.extract(member, dirname)
-                output_tf.add(abspath(f"{dirname}/{member.name}"), arcname=member.name.split('/')[-1])
-    tf.close()
-    output_tf.close()
-    return output_file
-
-
-def parse_args():
-    parser = ArgumentParser(description="Generate codec codes of waveforms (WebDataset-style tar in, tar out).")
-    parser.add_argument("--input_file", type=str, required=True, help="Path to the input tar (24 kHz PCM-16 .wav + .txt members).")
-    parser.add_argument("--batch_size", type=int, default=32, help="Batch size of the Encodec encode.")
-    parser.add_argument("--max_duration", type=int, default=12, help="Every waveform is zero-padded to this many seconds.")
-    parser.add_argument("--weights", type=str, default=None, help="encodec state_dict (.pt); seeded random weights otherwise")
-    parser.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    return parser.parse_args()
+    """x.tar -> x_processed.tar: per utterance `<utt>.npy` (int64 [8, T]) and `<utt>.len.txt`, then every text member
+    unchanged at the end of the archive (the on-disk layout of generate_code.py:54-85; members are written from memory)."""
+    out_path = input_file[:-4] + "_processed.tar" if input_file.endswith(".tar") else input_file + "_processed.tar"
+    with tarfile.open(input_file, "r") as src, tarfile.open(out_path, "w") as dst:
+        members = src.getmembers()
+        for wavs, names, lengths in create_batch(members, src, batch_size, max_duration):
+            for code, name, n_frames in zip(generate(wavs), names, lengths):
+                stem = name.split("/")[-1].replace(".wav", "")
+                buf = io.BytesIO()
+                np.save(buf, code)
+                _add_bytes(dst, stem + ".npy", buf.getvalue())
+                _add_bytes(dst, stem + ".len.txt", str(n_frames).encode())
+        for m in members:
+            if m.isfile() and ".txt" in m.name:
+                _add_bytes(dst, m.name.split("/")[-1], src.extractfile(m).read())
+    return out_path
 
 
 if __name__ == "__main__":
-    args = parse_args()
-    load_encoder(args.weights, torch.float32 if args.dtype == "f32" else torch.bfloat16)
-    print(main(args.input_file, args.batch_size, args.max_duration))
+    cli = ArgumentParser(description="Waveforms -> Encodec codes (WebDataset-style tar in, tar out).")
+    cli.add_argument("--input_file", type=str, required=True, help="tar with 24 kHz PCM-16 .wav members (+ .txt transcripts)")
+    cli.add_argument("--batch_size", type=int, default=32, help="waveforms per encode call")
+    cli.add_argument("--max_duration", type=int, default=12, help="seconds every waveform is zero-padded to")
+    cli.add_argument("--weights", type=str, default=None, help="encodec state_dict (.pt); seeded random weights otherwise")
+    cli.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ns = cli.parse_args()
+    load_encoder(ns.weights, torch.float32 if ns.dtype == "f32" else torch.bfloat16)
+    print(main(ns.input_file, ns.batch_size, ns.max_duration))
