@@ -33,7 +33,7 @@ def positional_table(seq_len_cfg, S, d, inv_freq=None):
         raise RuntimeError(f"text length {S} exceeds positional channels {ch}")
     if inv_freq is None:
         inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
-    ang = torch.arange(d, dtype=inv_freq.dtype)[:, None] * inv_freq[None, :]      # (d, ch/2)
+    ang = torch.arange(d, dtype=inv_freq.dtype, device=inv_freq.device)[:, None] * inv_freq[None, :]      # (d, ch/2)
     tab = torch.stack((ang.sin(), ang.cos()), dim=-1).flatten(-2, -1)             # (d, ch)
     return tab[:, :S].transpose(0, 1).contiguous()                                # (S, d)
 

@@ -82,6 +82,7 @@ class ParamStore:
         self.seg_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.arena = None               # ZeroArena, created on first fused step
         self.arena_active = None        # set by the fused loss+backward path only (forward and backward are one episode)
+        self.shadow_dirty = True
         with torch.no_grad():
             for p in self.params:
                 i = self.info[id(p)]
@@ -152,11 +153,17 @@ class ParamStore:
 
     def refresh_shadow(self):
         ops.pack_shadow(self.flat_p, self.shadow, self.seg_dev, self.n_seg)
-        self._shadow_version = self.flat_p._version
+        self.shadow_dirty = False
+
+    def mark_dirty(self):
+        """The master weights may have been written outside the fused AdamW kernel (load_state_dict, a torch optimizer
+        stepping through the parameter views after loss.backward(), manual edits): the activation-dtype shadow the GEMM /
+        conv kernels read must be repacked before the next forward.  An explicit flag, because `p.data = view` gives every
+        Parameter its own version counter -- writes through the views never show up in flat_p._version."""
+        self.shadow_dirty = True
 
     def ensure_shadow_fresh(self):
-        # torch optimizers / load_state_dict write through the parameter views and bump the shared version
-        if self.flat_p._version != self._shadow_version:
+        if self.shadow_dirty:
             self.refresh_shadow()
 
     def zero_grad(self):
@@ -170,8 +177,10 @@ class ParamStore:
             gnorm_sq = torch.zeros(1, dtype=torch.float32, device=self.device)
             ops.sumsq(self.flat_g, gnorm_sq)
         self.step_count += 1
+        self.ensure_shadow_fresh()       # frozen tensors keep their shadow: it must be current before the fused refresh
         ops.adamw_step(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.shadow, self.seg_dev, self.n_seg,
                        gnorm_sq, max_norm, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
+        self.shadow_dirty = False        # the kernel rewrote the shadow of every updated tensor
         return gnorm_sq
 
 

@@ -227,11 +227,50 @@ class SyntheticDataset(Dataset):
         return self.item_list[idx]
 
 
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """This rank's share of the batches of one epoch, INDEX lists only (nothing is collated for other ranks).
+
+    Same policy as the batch-sampler shard accelerate wraps around the reference's DataLoader (train.py:67-69; no drop_last,
+    even batches): the epoch's index order is cut into batches of `batch_size`, rank r takes batches r, r + W, r + 2W, ...;
+    a short final batch is completed, and the batch count rounded up to a multiple of W, with indices taken again from the
+    START of the epoch's order, so every rank runs the same number of full-size steps (no rank is left alone inside a
+    collective at the end of an epoch).  Every rank must draw the same order: seed the sampler's generator identically."""
+
+    def __init__(self, sampler, batch_size, rank=0, world=1):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.sampler, self.batch_size, self.rank, self.world = sampler, int(batch_size), int(rank), int(world)
+
+    def __len__(self):
+        n_batches = -(-len(self.sampler) // self.batch_size)
+        return -(-n_batches // self.world) if n_batches else 0
+
+    def __iter__(self):
+        order = list(self.sampler)
+        if not order:
+            return
+        bs, W = self.batch_size, self.world
+        n_batches = -(-len(order) // bs)
+        n_even = -(-n_batches // W) * W
+        need = n_even * bs - len(order)          # indices to borrow from the start of the order (cyclically if tiny)
+        k = 0
+        while need > 0:
+            order.append(order[k]); k += 1; need -= 1
+        for b in range(self.rank, n_even, W):
+            yield order[b * bs:(b + 1) * bs]
+
+
 def create_dataloader(data_file, batch_size, max_seq_length, shuffle=False, text_to_ids=None, dataset=None, lazy=False,
-                      num_workers=0):
+                      num_workers=0, rank=0, world=1):
     """Reference signature first (dataloader.py:191-198); `lazy=True` reads utterances on demand from an offset index instead of
-    loading the whole tar, `num_workers` collates in background processes."""
+    loading the whole tar, `num_workers` collates in background processes; `world` > 1 hands this rank only its own batches
+    (ShardedBatchSampler) -- the sharding accelerate.prepare applies to the reference's loader."""
     if dataset is None:
         dataset = (LazySingleSpeakerDataset if lazy else SingleSpeakerDataset)(data_file, text_to_ids)
-    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=TTS_SingleSpkr_Collate_Fn(max_seq_length),
+    collate = TTS_SingleSpkr_Collate_Fn(max_seq_length)
+    if world > 1:
+        sampler = torch.utils.data.RandomSampler(dataset) if shuffle else torch.utils.data.SequentialSampler(dataset)
+        return DataLoader(dataset, batch_sampler=ShardedBatchSampler(sampler, batch_size, rank, world), collate_fn=collate,
+                          num_workers=num_workers, persistent_workers=num_workers > 0)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=collate,
                       num_workers=num_workers, persistent_workers=num_workers > 0)

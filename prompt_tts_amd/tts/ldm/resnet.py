@@ -97,7 +97,10 @@ class ResnetBlock1D(nn.Module):
                                  st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True, arena=st.arena_active)
         # time-embedding projection: d tproj[b][c] = sum_n dh1[(b,n)][c]  (its GEMMs are batched over all blocks by the UNet)
         ops.colsum(dh1, dtproj, M, Cout, seg_rows=N, ld_out=dtproj.stride(0))
-        da1 = E.conv3_bwd(dh1, a1, st.w(self.conv1.weight), st.g(self.conv1.weight), None, B, N, N, cin=Cin, cout=Cout)
+        # conv1.bias: its gradient is complete here, BEFORE the block is announced to the data-parallel reducer (it rides on
+        # the wgrad GEMM's all-ones column like every other bias)
+        da1 = E.conv3_bwd(dh1, a1, st.w(self.conv1.weight), st.g(self.conv1.weight), st.g(self.conv1.bias), B, N, N,
+                          cin=Cin, cout=Cout)
         if self.conv_shortcut is not None:
             w, gw = st.w(self.conv_shortcut.weight), st.g(self.conv_shortcut.weight).view(Cout, Cin)
             A = ops.concat(x1, x2, trans=True) if x2 is not None else ops.plain(x1, trans=True)

@@ -177,17 +177,6 @@ class Unet1DConditionModel(nn.Module):
         tape["dims"] = (B, T, S)
         return pred, tape
 
-    def _conv1_bias_index(self, st):
-        """flat-gradient indices of every resnet's conv1.bias, in time-projection column order."""
-        idx = getattr(self, "_c1b_idx", None)
-        if idx is None or idx.device != st.flat_g.device:
-            parts = []
-            for r in self._resnets:
-                off = st.info[id(r.conv1.bias)]["off"]
-                parts.append(torch.arange(off, off + r.out_channels, dtype=torch.int64))
-            idx = self._c1b_idx = torch.cat(parts).to(st.flat_g.device)
-        return idx
-
     # ---- backward -------------------------------------------------------------------------------------------
     def bwd(self, st, tape, dpred, on_ready=None):
         """dpred: (B*T, cpad) (pad channels zero).  Returns dctx (B*S, d).  `on_ready(module)` fires when every
@@ -247,16 +236,14 @@ class Unet1DConditionModel(nn.Module):
         E.conv3_bwd(dh, xt, st.w(self.conv_in.weight), st.g(self.conv_in.weight), st.g(self.conv_in.bias), B, T, T,
                     cin=self.cpad, cout=C0, cin_store=cfg["in_channels"], need_dx=False)
         notify(self.conv_in)
-        # batched time-embedding projection backward: one dgrad + one wgrad + one column sum for all resnets; each
-        # conv1 bias gradient equals its slice of the projection-bias gradient (both are sum_b dtproj[b][c])
+        # batched time-embedding projection backward: one dgrad + one wgrad + one column sum for all resnets.  The packed
+        # time_emb_proj tensors live in the "late" region of the flat buffers, which no block span covers: the data-parallel
+        # reducer picks that region up in finish(), after these writes.
         Wt, gWt, _, gbt = st.late_views()
         dsemb = E.linear_bwd(dtp_all, semb, Wt, gWt, None)
-        bsum = torch.zeros(self._tp_total, dtype=torch.float32, device=dtp_all.device)
-        for c0 in range(0, self._tp_total, 8192):                    # one column sum serves every pair of bias vectors
+        for c0 in range(0, self._tp_total, 8192):                    # projection-bias gradients: column sums over the batch
             c1 = min(self._tp_total, c0 + 8192)
-            ops.colsum(dtp_all[:, c0:c1], bsum[c0:c1], B, c1 - c0)
-        gbt += bsum
-        st.flat_g.index_add_(0, self._conv1_bias_index(st), bsum)
+            ops.colsum(dtp_all[:, c0:c1], gbt[c0:c1], B, c1 - c0)
         # time-embedding MLP backward (f32)
         te = self.time_embedding
         demb = torch.empty_like(emb); ops.silu_bwd(dsemb, emb, demb)

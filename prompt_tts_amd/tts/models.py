@@ -130,6 +130,8 @@ class TTSSingleSpeaker(nn.Module):
         self._anchor = None
         self._alphas_cumprod = None
         self.grad_ready_hook = None      # set by the data-parallel reducer
+        # load_state_dict writes through the parameter views: the kernel-layout weight shadow must be repacked afterwards
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
     # ---- device state --------------------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):
@@ -147,6 +149,12 @@ class TTSSingleSpeaker(nn.Module):
             self._store = E.ParamStore(self, p0.device, self.compute_dtype)
             self._anchor = torch.zeros(1, device=p0.device, requires_grad=True)
         return self._store
+
+    def refresh_weights(self):
+        """Call after writing parameters by any route this module cannot see (direct edits of `p.data`); load_state_dict,
+        `loss.backward()` followed by a torch optimizer, and the fused AdamW are tracked automatically."""
+        if self._store is not None:
+            self._store.mark_dirty()
 
     def alphas_cumprod(self, device):
         """DDPMScheduler(1000, linear 1e-4..0.02) cumulative alphas (train.py:32-36), f32."""
@@ -227,6 +235,7 @@ class TTSSingleSpeaker(nn.Module):
 
     def _backward_impl(self, tape, dout):
         st = self.store
+        st.mark_dirty()                  # autograd path: a torch optimizer is about to step through the parameter views
         _, _, B, T, S = tape
         n_q, cpad = self.config["in_channels"], self.unet.cpad
         dpred = torch.empty(B * T, cpad, dtype=st.dtype, device=st.device)

@@ -1,0 +1,165 @@
+"""Parity of the GEMM kernels at the sizes the benchmark actually runs (BASELINE configs[1]).
+
+pick_tile (csrc/gemm.hip) moves bf16 forward / dgrad / conv GEMMs to the 256x256 eight-phase kernel once a problem has
+>= 192 tiles of 256x256, and the weight-gradient GEMMs run split-K over a 32 768-row reduction: none of that is reached by the
+small shapes of tests/test_kernels_gpu.py.  Every class the training step launches is checked here at such sizes, including
+M / N / K that are not multiples of the 256 / 64 tile edges.
+
+Reference: a plain PyTorch f32 matmul of the SAME bf16-rounded inputs, evaluated on the device (rocBLAS: an independent
+implementation; a CPU matmul of these sizes would take minutes).  Conv references are built from explicit shifted copies of
+the input (no im2col inside the kernel under test).  Tolerance: TOL below, as in test_kernels_gpu.py.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 1.5e-2}
+
+
+def _ops():
+    from prompt_tts_amd import ops, _lib
+    return ops, _lib
+
+
+def relerr(got, ref):
+    got = got.detach().float(); ref = ref.detach().float()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+def rnd(shape, dtype, dev, gen, scale=1.0):
+    x = (torch.randn(shape, generator=gen, device=dev) * scale).to(dtype)
+    return x, x.float()
+
+
+def _gen(dev, seed):
+    return torch.Generator(device=dev).manual_seed(seed)
+
+
+def tiles256(M, N):
+    return ((M + 255) // 256) * ((N + 255) // 256)
+
+
+# ---- forward NN / dgrad NT, plain operands --------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(32768, 512, 512), (32768, 1536, 512), (32768, 4096, 512), (32768, 512, 2048),
+                                   (8200, 1544, 520), (12288, 4096, 2048)])
+def test_forward_plain_large(dev, M, N, K):
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    assert tiles256(M, N) >= 192
+    g = _gen(dev, 1)
+    a, af = rnd((M, K), dtype, dev, g); w, wf = rnd((N, K), dtype, dev, g, K ** -0.5)
+    r, rf = rnd((M, N), dtype, dev, g); bias = torch.randn(N, generator=g, device=dev)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(M, N, K, ops.plain(a), ops.plain(w), out, ops.pt_dtype(a), bias=bias, residual=r, ldr=N)
+    assert relerr(out, af @ wf.t() + bias + rf) < TOL[dtype]
+
+
+@pytest.mark.parametrize("M,Nout,Kin", [(32768, 512, 512), (32768, 1536, 512), (32768, 4096, 512), (32768, 512, 2048),
+                                        (8200, 520, 1544)])
+def test_dgrad_plain_large(dev, M, Nout, Kin):
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    assert tiles256(M, Kin) >= 192 or (M, Kin) == (32768, 512)
+    g = _gen(dev, 2)
+    dy, dyf = rnd((M, Nout), dtype, dev, g); w, wf = rnd((Nout, Kin), dtype, dev, g, Nout ** -0.5)
+    acc, accf = rnd((M, Kin), dtype, dev, g)
+    dx = acc.clone()
+    ops.gemm(M, Kin, Nout, ops.plain(dy), ops.plain(w, trans=True), dx, ops._DT[dtype], residual2=dx, ldr2=Kin)  # in-place accumulate
+    assert relerr(dx, dyf @ wf + accf) < TOL[dtype]
+
+
+# ---- conv k3 forward (stride 1 / stride 2 / upsample-fused) and dgrad -----------------------------------------------------
+def _conv_ref(xf, w3f, B, n_in, mode):
+    """xf (B*n_in, cin) f32 token-major; w3f [cout][3][cin] f32.  Returns (B*n_out, cout) f32."""
+    cin = xf.shape[1]
+    x = xf.view(B, n_in, cin)
+    if mode == "up2":
+        x = x.repeat_interleave(2, dim=1)
+    z = torch.zeros(B, 1, cin, device=xf.device)
+    xp = torch.cat([z, x, z], dim=1)                                      # pad 1 on both sides
+    n = x.shape[1]
+    cols = torch.cat([xp[:, 0:n], xp[:, 1:n + 1], xp[:, 2:n + 2]], dim=2)   # tap-major [.., 3*cin]
+    if mode == "s2":
+        cols = cols[:, ::2]
+    return cols.reshape(-1, 3 * cin) @ w3f.reshape(w3f.shape[0], -1).t()
+
+
+@pytest.mark.parametrize("mode,B,n_in,cin,cout", [("s1", 32, 1024, 512, 512), ("s2", 64, 1024, 512, 512),
+                                                  ("up2", 32, 512, 512, 512), ("s1", 25, 1000, 520, 264),
+                                                  ("s1", 32, 1024, 1024, 512)])
+def test_conv_forward_large(dev, mode, B, n_in, cin, cout):
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 3)
+    n_out = {"s1": n_in, "s2": (n_in - 1) // 2 + 1, "up2": 2 * n_in}[mode]
+    rowmap = {"s1": L.PT_MAP_S1, "s2": L.PT_MAP_S2, "up2": L.PT_MAP_UP2}[mode]
+    assert tiles256(B * n_out, cout) >= 192
+    x, xf = rnd((B * n_in, cin), dtype, dev, g); w3, w3f = rnd((cout, 3, cin), dtype, dev, g, (3 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g, device=dev); temb = torch.randn(B, cout, generator=g, device=dev)
+    res, resf = rnd((B * n_out, cout), dtype, dev, g)
+    out = torch.full((B * n_out, cout), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(B * n_out, cout, 3 * cin, ops.conv(x, cin, n_out, n_in, rowmap), ops.plain(w3.view(cout, 3 * cin)), out, ops._DT[dtype],
+             bias=bias, row_bias=temb, row_bias_rows=n_out, residual=res, ldr=cout)
+    ref = _conv_ref(xf, w3f, B, n_in, mode) + bias + temb.repeat_interleave(n_out, dim=0) + resf
+    assert relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("mode,B,n_in,cin,cout", [("s1", 32, 1024, 512, 512), ("s2", 64, 1024, 512, 512),
+                                                  ("s1", 25, 1000, 264, 520)])
+def test_conv_dgrad_large(dev, mode, B, n_in, cin, cout):
+    """dx = conv^T(dy): checked through autograd of the explicit-copies reference."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 4)
+    n_out = n_in if mode == "s1" else (n_in - 1) // 2 + 1
+    assert tiles256(B * n_in, cin) >= 192
+    w3, w3f = rnd((cout, 3, cin), dtype, dev, g, (3 * cin) ** -0.5)
+    dy, dyf = rnd((B * n_out, cout), dtype, dev, g)
+    xz = torch.zeros(B * n_in, cin, device=dev, requires_grad=True)
+    _conv_ref(xz, w3f, B, n_in, mode).backward(dyf)
+    dx = torch.full((B * n_in, cin), float("nan"), dtype=dtype, device=dev)
+    rowmap = L.PT_MAP_S1 if mode == "s1" else L.PT_MAP_S2_DGRAD
+    ops.gemm(B * n_in, cin, 3 * cout, ops.conv(dy, cout, n_in, n_out, rowmap), ops.wflip(w3, cout, cin), dx, ops._DT[dtype])
+    assert relerr(dx, xz.grad) < TOL[dtype]
+
+
+# ---- weight gradients at the benchmark's reduction length (split-K) ---------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("Mred,Nout,Kin", [(32768, 512, 512), (32768, 1536, 512), (32768, 4096, 512), (32768, 512, 2048),
+                                           (16384, 512, 1024), (8200, 520, 264)])
+def test_wgrad_plain_large(dev, dtype, Mred, Nout, Kin):
+    from prompt_tts_amd import engine as E
+    ops, L = _ops()
+    if dtype == torch.float32 and Nout * Kin > 1536 * 512:
+        pytest.skip("f32 parity mode is exercised at the smaller shapes")
+    g = _gen(dev, 5)
+    dy, dyf = rnd((Mred, Nout), dtype, dev, g); x, xf = rnd((Mred, Kin), dtype, dev, g)
+    dw = torch.ones(Nout, Kin, dtype=torch.float32, device=dev)            # accumulates on top of existing gradients
+    gb = torch.zeros(Nout, dtype=torch.float32, device=dev)
+    ops.gemm(Nout, Kin, Mred, ops.plain(dy, trans=True), ops.plain(x, trans=True), dw, ops._DT[dtype],
+             out_kind=L.PT_OUT_F32_ATOMIC, split_k=E._split_k(Nout, Kin, Mred, dtype), arow_sum=gb, arow_n=Nout)
+    ref = dyf.t() @ xf
+    assert relerr(dw - 1.0, ref) < TOL[dtype]
+    assert relerr(gb, dyf.sum(0)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("mode,B,n_in,cin,cout", [("s1", 32, 1024, 512, 512), ("s1", 32, 1024, 1024, 512),
+                                                  ("s2", 32, 1024, 512, 512), ("up2", 32, 512, 512, 512)])
+def test_wgrad_conv_large(dev, mode, B, n_in, cin, cout):
+    from prompt_tts_amd import engine as E
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 6)
+    n_out = {"s1": n_in, "s2": (n_in - 1) // 2 + 1, "up2": 2 * n_in}[mode]
+    rowmap = {"s1": L.PT_MAP_S1, "s2": L.PT_MAP_S2, "up2": L.PT_MAP_UP2}[mode]
+    x, xf = rnd((B * n_in, cin), dtype, dev, g); dy, dyf = rnd((B * n_out, cout), dtype, dev, g)
+    wz = torch.zeros(cout, 3, cin, device=dev, requires_grad=True)
+    _conv_ref(xf, wz, B, n_in, mode).backward(dyf)
+    dw = torch.zeros(cout, 3 * cin, dtype=torch.float32, device=dev)
+    gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+    ops.gemm(cout, 3 * cin, B * n_out, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True), dw,
+             ops._DT[dtype], ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=E._split_k(cout, 3 * cin, B * n_out, dtype),
+             arow_sum=gb, arow_n=cout)
+    assert relerr(dw.view(cout, 3, cin), wz.grad) < TOL[dtype]
+    assert relerr(gb, dyf.sum(0)) < TOL[dtype]

@@ -212,3 +212,40 @@ def test_train_lr_lambda_matches_oracle():
     for name in ("constant", "constant_with_warmup", "linear", "cosine"):
         f, g = ns["lr_lambda"](name, 5, 40), want(name, 5, 40)
         assert all(abs(f(s) - g(s)) < 1e-12 for s in range(0, 45))
+
+
+@pytest.mark.parametrize("n_items,bs,world", [(23, 4, 2), (23, 4, 3), (16, 4, 2), (5, 4, 4), (1, 8, 2), (33, 8, 8)])
+def test_sharded_batch_sampler_equal_full_batches(n_items, bs, world):
+    """accelerate's policy for the reference's loader (train.py:67-69): rank r takes batches r, r+W, ...; the tail wraps
+    around to the start of the epoch's order so every rank runs the same number of full-size steps (an odd batch count used
+    to leave the low ranks alone inside a collective at the end of an epoch)."""
+    from prompt_tts_amd.tts.dataloader import ShardedBatchSampler
+    order = list(np.random.default_rng(3).permutation(n_items))
+    shards = [list(ShardedBatchSampler(order, bs, r, world)) for r in range(world)]
+    n_batches = -(-n_items // bs)
+    per_rank = -(-n_batches // world)
+    assert all(len(s) == per_rank == len(ShardedBatchSampler(order, bs, r, world)) for r, s in enumerate(shards))
+    assert all(len(b) == bs for s in shards for b in s)                       # every step has the full per-rank batch
+    # interleaving the ranks' batches gives back the epoch order, then its beginning again (wrap-around)
+    flat = [i for k in range(per_rank) for r in range(world) for i in shards[r][k]]
+    assert flat[:n_items] == order
+    cyc = (order * (len(flat) // n_items + 2))
+    assert flat[n_items:] == cyc[:len(flat) - n_items]
+    with pytest.raises(ValueError):
+        ShardedBatchSampler(order, bs, world, world)
+
+
+def test_create_dataloader_shards_indices_not_collated_batches():
+    from prompt_tts_amd.tts.dataloader import SyntheticDataset, create_dataloader
+    ds = SyntheticDataset(10, 2, 16, max_text=32)
+    calls = []
+    orig = ds.__class__.__getitem__
+    class Counting(ds.__class__):
+        def __getitem__(self, i):
+            calls.append(i); return orig(self, i)
+    ds.__class__ = Counting
+    dl = create_dataloader(None, 4, 32, shuffle=False, dataset=ds, rank=1, world=2)
+    batches = list(dl)
+    assert len(batches) == len(dl) == 2 and all(b["code"].shape[0] == 4 for b in batches)
+    # 10 items, batches of 4, 2 ranks: [0..3] [4..7] [8,9,0,1] [2,3,4,5]; rank 1 reads ONLY its own two batches
+    assert calls == [4, 5, 6, 7, 2, 3, 4, 5]

@@ -189,3 +189,43 @@ def test_full_size_config_b_batch_items_are_independent(dev, dtype, tol):
         for b in range(3):
             one = m(noise[b:b + 1], t[b:b + 1], ids[b:b + 1], mask[b:b + 1]).sample
             assert relerr(one, full[b:b + 1]) < tol, b
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_weight_shadow_follows_load_state_dict_and_torch_optimizer(dev, dtype, tol):
+    """The kernels read an activation-dtype, kernel-layout SHADOW of the GEMM / conv weights.  It must follow every route that
+    writes the master weights: load_state_dict on a model whose store already exists (train.py --resume_epoch), and a stock
+    torch optimizer stepping through the parameter views after loss.backward() (INTEGRATION.md drop-in flow)."""
+    from oracle.init import deterministic_init_
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    z, cfg = load("small256")
+    xt = torch.from_numpy(z["xt"]).to(dev); t = torch.from_numpy(z["t"]).to(dev)
+    ids = torch.from_numpy(z["ids"]).to(dev); mask = torch.from_numpy(z["mask"]).to(dev); noise = torch.from_numpy(z["noise"]).to(dev)
+    a = build(cfg, 1, dtype, dev)
+    with torch.no_grad():
+        out_a = a(xt, t, ids, mask).sample                       # the store (and its shadow) exists now
+    b = build(cfg, 2, dtype, dev)                                # different weights everywhere
+    with torch.no_grad():
+        want_b = b(xt, t, ids, mask).sample
+    assert relerr(out_a, want_b) > 1e-2
+    a.load_state_dict(b.state_dict())
+    with torch.no_grad():
+        got = a(xt, t, ids, mask).sample
+    assert relerr(got, want_b) < tol                             # GEMM weights AND biases are the loaded ones
+    # one step of a stock optimizer: the next forward must equal a freshly built model holding the stepped weights
+    opt = torch.optim.SGD(a.parameters(), lr=0.5)
+    F.mse_loss(a(xt, t, ids, mask).sample, noise).backward()
+    opt.step()
+    with torch.no_grad():
+        stepped = a(xt, t, ids, mask).sample
+    fresh = TTSSingleSpeaker(cfg, dtype=dtype)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in a.state_dict().items()})
+    fresh = fresh.to(dev)
+    with torch.no_grad():
+        want = fresh(xt, t, ids, mask).sample
+    assert relerr(stepped, want) < tol
+    assert relerr(stepped, want_b) > 1e-4                        # and the step did change the function
+    # the fused path after an external write: same result as the fresh model's fused step
+    l1, _ = a.train_step(xt, noise, t, ids, mask)
+    l2, _ = fresh.train_step(xt, noise, t, ids, mask)
+    assert abs(float(l1) - float(l2)) < tol * abs(float(l2))

@@ -9,7 +9,8 @@ Differences from the reference, all behind the same surface: the step is the fus
 (TTSSingleSpeaker.train_step: add_noise -> forward -> MSE -> backward -> clip -> AdamW, no host sync except the
 logged loss), data parallelism is a bucketed RCCL all-reduce of the flat grad buffer overlapped with backward
 (prompt_tts_amd/parallel.py) instead of DDP(find_unused_parameters=True), and the batch sharding follows
-accelerate's BatchSamplerShard round-robin (rank r takes batches r, r+W, ...).
+accelerate's round-robin over batches (rank r takes batches r, r+W, ...; the tail wraps around so that every rank
+runs the same number of steps) at the INDEX level: a rank collates only its own batches.
 """
 import argparse
 import json
@@ -26,19 +27,6 @@ from prompt_tts_amd.tts.models import TTSSingleSpeaker
 logging.basicConfig(format="%(asctime)s - %(levelname)s: %(message)s", level=logging.INFO, datefmt="%I:%M:%S")
 
 ADAMW = dict(lr=1e-5, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)      # hard-coded in the reference (train.py:41-47)
-
-
-class _Sized:
-    """An iterable with a known length (the rank's share of the batches)."""
-
-    def __init__(self, it, n):
-        self.it, self.n = it, n
-
-    def __iter__(self):
-        return iter(self.it)
-
-    def __len__(self):
-        return self.n
 
 
 def lr_lambda(name, num_warmup_steps, num_training_steps):
@@ -76,9 +64,9 @@ def main(args):
     reducer = parallel.attach(model) if world > 1 else None
     ds = SyntheticDataset(args.synthetic, config["in_channels"], config["sample_size"], args.max_seq_length) if args.synthetic else None
     dataloader = create_dataloader(args.data_file, args.batch_size, args.max_seq_length, shuffle=True, dataset=ds,
-                                   lazy=args.lazy_tar, num_workers=args.num_workers)
+                                   lazy=args.lazy_tar, num_workers=args.num_workers, rank=rank, world=world)
     accum = config["gradient_accumulation_steps"]
-    steps_per_epoch = math.ceil(math.ceil(len(dataloader) / world) / accum)
+    steps_per_epoch = math.ceil(len(dataloader) / accum)             # len(dataloader) = this rank's batches (equal on all ranks)
     max_train_steps = config["num_train_epochs"] * steps_per_epoch
     lam = lr_lambda(config["lr_scheduler"], config["lr_warmup_steps"] * accum, max_train_steps * accum)
     st = model.store
@@ -103,9 +91,9 @@ def main(args):
         torch.manual_seed(epoch)                                            # same shuffle on every rank (accelerate C7)
         micro = 0
         loss_acc = torch.zeros(1, device=dev)
-        # BatchSamplerShard round-robin over batches; this rank's batches are pinned and copied ahead of the step loop
-        mine = (b for bi, b in enumerate(dataloader) if bi % world == rank)
-        for batch in (DeviceFeeder(_Sized(mine, math.ceil(len(dataloader) / world)), dev) if args.prefetch else mine):
+        # this rank's batches only (ShardedBatchSampler), pinned and copied to the GPU ahead of the step loop
+        n_batches = len(dataloader)
+        for bi, batch in enumerate(DeviceFeeder(dataloader, dev) if args.prefetch else dataloader):
             codes = batch["code"].to(dev)
             ids = batch["cmu_sequence_id"].to(dev); mask = batch["attention_mask"].to(dev)
             noise = torch.randn(codes.shape, device=dev, generator=gen)
@@ -114,12 +102,15 @@ def main(args):
                 st.zero_grad()
                 if reducer is not None:
                     reducer.begin()
-            model.grad_ready_hook = reducer.on_ready if (reducer is not None and micro == accum - 1) else None
+            # the optimizer steps every `accum` micro-batches AND on the last batch of the epoch (accelerate syncs at
+            # end_of_dataloader), so leftover micro-batches are never dropped
+            sync = micro == accum - 1 or bi == n_batches - 1
+            model.grad_ready_hook = reducer.on_ready if (reducer is not None and sync) else None
             model.loss_and_backward(codes, noise, t, ids, mask, loss_out=loss_acc,
                                     grad_scale=1.0 / (accum * world))
             micro += 1
             global_step += 1
-            if micro == accum:
+            if sync:
                 if reducer is not None:
                     reducer.finish()
                 st.adamw_step(ADAMW["lr"] * lam(opt_step), ADAMW["betas"], ADAMW["eps"], ADAMW["weight_decay"], 1.0)
