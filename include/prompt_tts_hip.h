@@ -99,6 +99,18 @@ typedef struct pt_gemm_desc {
 
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
 
+/* Grouped weight gradients (bf16): up to 8 GEMMs dW_i (+)= alpha_i dY_i^T X_i in ONE launch + one fold launch.
+ * Replaces the autograd weight-gradient ops of one transformer block / resnet of the reference (the backward of the nn.Linear
+ * and Conv1d modules at tts/ldm/resnet.py:171,193,226-228, transformer_1d.py:134 and the diffusers Attention / FeedForward
+ * linears) -- small outputs under an 8 192..32 768-token reduction.  Each descriptor is a pt_gemm weight-gradient descriptor:
+ * out_kind = PT_OUT_F32_ATOMIC, A = dY (PT_V_PLAIN, trans = 1), B = X (trans = 1; all PT_V_PLAIN / PT_V_CONCAT or all
+ * PT_V_CONV within one group), C = f32 gradient [M][ldc] accumulated in place (16-byte aligned rows preferred), optional
+ * arow_sum bias gradient; split_k is chosen by the library so that the group's 256 x 256 tiles x K-slices fill `target_wgs`
+ * workgroups (<= 0: 256, one per CU).  `ws` = f32 scratch for the split-K partial tiles, ws_floats >=
+ * pt_wgrad_group_ws_floats(target_wgs); the caller owns it and must not touch it until the stream has passed the call. */
+int64_t pt_wgrad_group_ws_floats(int target_wgs);
+int pt_wgrad_group(const pt_gemm_desc* descs, int n, float* ws, int64_t ws_floats, int target_wgs, pt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Attention (non-causal or causal, no padding mask unless kv_len given), flash-style, f32 softmax.
  * q: [B*Nq][ldq] with head h at columns [h*D, (h+1)*D); k, v likewise over B*Nk rows.

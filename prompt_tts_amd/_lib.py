@@ -72,6 +72,7 @@ _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 # name -> argtypes (all return int status unless noted); mirrors include/prompt_tts_hip.h one to one.
 SIGNATURES = {
     "pt_gemm": [C.POINTER(pt_gemm_desc), _i32, _vp],
+    "pt_wgrad_group": [C.POINTER(pt_gemm_desc), _i32, _vp, _i64, _i32, _vp],
     "pt_attn_fwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_attn_bwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
@@ -121,6 +122,8 @@ def _load():
     lib.pt_status_string.argtypes = [C.c_int]
     lib.pt_struct_size.restype = C.c_int
     lib.pt_struct_size.argtypes = [C.c_int]
+    lib.pt_wgrad_group_ws_floats.restype = C.c_int64
+    lib.pt_wgrad_group_ws_floats.argtypes = [C.c_int]
     for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")

@@ -546,22 +546,20 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
 // =====================================================================================================================
 constexpr int P8_UNIT = 16384, P8_BUF = 4 * P8_UNIT, P8_THREADS = 512;
 
-template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
-__global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams p) {
+// OUT: 0 = store epilogue (bias / residual / activation), 1 = f32 atomics into C, 2 = SLAB: the workgroup's raw 256 x 256 f32
+// partial tile goes to `slab` with whole-wave 1 KiB stores (pt_wgrad_group: split-K partials summed by wgrad_fold_kernel).
+// `bid` is the workgroup's index inside its problem: tiles x split_k, K-slice major.
+template <bool TA, bool TB, int OUT, int KA, int KB>
+__device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, float* __restrict__ slab, char* smem) {
   using T = bf16_t;
+  constexpr bool ATOMIC = OUT == 1;            // accumulator orientation D[row = m][col = n] (contiguous n per atomic)
   constexpr int BM = 256, BN = 256, BK = 64, EPC = 8;
-  __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];     // the ONLY LDS object (epilogue scratch aliases it)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int g = lane >> 4, li = lane & 15;
 
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   // grid.x = tiles x split_k, K-slice major: the run of ids an XCD owns is (nearly) one K-slice of every tile, so a split-K
   // wgrad streams each operand through one L2 once (tile-major slices made every XCD re-fetch whole panels: 3x the bytes)
   const int ntile = p.tiles_m * p.tiles_n;
@@ -581,6 +579,15 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // SLAB mode: the bias gradient sum_k VA(m,k) as an all-ones MFMA product, in the first tile column's workgroups; the 128
+  // rows of a wave-row are shared out over its four waves (wave-column wc takes the 16-row block wc of each 64-row half)
+  const bool do_sum = OUT == 2 && p.arow_sum != nullptr && tn == 0;
+  f32x4_t accb[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+  Frag<T> fones;
+  {
+    const float one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    frag_from_f32(fones, one8);
+  }
 
   // ---- staging state: unit U = 2 * operand + half; two 16-byte chunks per thread per unit ----
   const char* ptr[4][2]; uint32_t stp[4][2]; int cnt[4] = {0, 0, 0, 0};
@@ -633,6 +640,28 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
   integral_constant<int, 0> OA, H0; integral_constant<int, 1> OB, H1;
 
   Frag<T> fa[4][2], fb0[2][2], fb1[2][2];
+  // Transposed (TileT<128>) fragment addresses from ONE lane-dependent base per operand.  For k = 32 ks + 8 g + 4 hi + q
+  // (q = (lane & 15) >> 2) the image swizzle is tilet_swz(k) = (q << 1) | ((hi ^ g) & 1) << 3, independent of ks, and a
+  // fragment's chunk index c = (16-column block) * 2 + (p >> 1) has its block number in bits the lane part never carries
+  // into, so   chunk_off(k, c) = [lane base] ^ (((2 blk) ^ (8 hi)) << 4)  +  (4 hi + 32 ks) * 256.
+  // The XOR is issued right at the read (one VALU each); written as plain chunk_off() calls, hipcc hoists all 2 buffers x
+  // 2 halves x 24 loop-invariant addresses out of the k loop and then spills the staging pointers INTO the loop, where every
+  // reload is followed by s_waitcnt vmcnt(0) and drains the LDS-DMA pipeline.
+  const int tq = li >> 2, tp = li & 3;
+  const int tswz = (tq << 1) | ((g & 1) << 3);
+  const int t_lane_a = (8 * g + tq) * 256 + ((((wr * 8) + (tp >> 1)) ^ tswz) << 4) + ((tp & 1) << 3);
+  const int t_lane_b = (8 * g + tq) * 256 + ((((wc * 4) + (tp >> 1)) ^ tswz) << 4) + ((tp & 1) << 3);
+  auto tr_frag = [&](Frag<T>& f, const char* img, int lane_base, int blk, int ks) {
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    int a_lo, a_hi;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_lo) : "v"(lane_base), "v"((2 * blk) << 4));
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_hi) : "v"(lane_base), "v"(((2 * blk) ^ 8) << 4));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a_lo + ks * 32 * 256));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a_hi + (ks * 32 + 4) * 256));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8_t, r);
+  };
   auto read_a = [&](const char* buf, int s) {
     const char* img = buf + s * P8_UNIT;
 #pragma unroll
@@ -641,7 +670,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
       for (int ks = 0; ks < 2; ++ks) {
         const int kb = ks * 32 + 8 * g;
         if (!TA) frag_load_k(fa[i][ks], img, wr * 64 + 16 * i + li, kb);
-        else     frag_load_t<128>(fa[i][ks], img, wr * 64 + 16 * i, kb, kb + 4, lane);
+        else     tr_frag(fa[i][ks], img, t_lane_a, i, ks);
       }
   };
   auto read_b = [&](Frag<T> (&fb)[2][2], const char* buf, int s) {
@@ -652,7 +681,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
       for (int ks = 0; ks < 2; ++ks) {
         const int kb = ks * 32 + 8 * g;
         if (!TB) frag_load_k(fb[j][ks], img, wc * 32 + 16 * j + li, kb);
-        else     frag_load_t<128>(fb[j][ks], img, wc * 32 + 16 * j, kb, kb + 4, lane);
+        else     tr_frag(fb[j][ks], img, t_lane_b, j, ks);
       }
   };
   // one output quadrant: rows 64 sa .. +63, columns 32 sb .. +31 of the wave's 128 x 64 tile, over the whole k-tile
@@ -671,6 +700,11 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
           if (ATOMIC) mma16(acc[4 * SA + i][2 * SB + j], fa[i][ks], fb[j][ks]);   // D[row = m][col = n]
           else        mma16(acc[4 * SA + i][2 * SB + j], fb[j][ks], fa[i][ks]);   // D[row = n][col = m]
         }
+    if (OUT == 2 && SB == 0 && do_sum) {       // phases 0 and 3: every column of the product is sum_k A[m][k]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (wc == i) { mma16(accb[SA], fones, fa[i][0]); mma16(accb[SA], fones, fa[i][1]); }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -729,7 +763,106 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams 
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
+  if (OUT == 2) {
+    // raw partial tile: register (i, j) of every wave is one whole-wave 1 KiB store; element r of lane l in it is
+    // C[m0 + wr*128 + 16 i + (l & 15)][n0 + wc*64 + 16 j + 4 (l >> 4) + r]  (decoded again by wgrad_fold_kernel)
+    float* dst = slab + ((size_t)wave * 32 * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(dst + (i * 4 + j) * 256) = acc[i][j];
+    if (do_sum && g == 0) {
+      float* bdst = p.arow_sum + (int64_t)(blockIdx.x % p.arow_rep) * p.arow_stride;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t m = m0 + wr * 128 + 64 * h + 16 * wc + li;
+        if (m < p.arow_n) unsafeAtomicAdd(bdst + m, p.alpha * accb[h][0]);
+      }
+    }
+    return;
+  }
   gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * SCRATCH_PER_WAVE);
+}
+
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
+  // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run of ids.  Bijective.
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];     // the ONLY LDS object (epilogue scratch aliases it)
+  gemm8p_body<TA, TB, ATOMIC ? 1 : 0, KA, KB>(p, xcd_contiguous_id(blockIdx.x, gridDim.x), nullptr, smem);
+}
+
+// =====================================================================================================================
+// Grouped weight gradients (pt_wgrad_group): ONE launch computes up to PT_WG_MAX weight-gradient GEMMs dW_p = dY_p^T X_p
+// (both operands read where they lie, reduction over tokens on the operand rows) on the eight-phase body above.
+// A weight gradient is a small output (4..32 tiles of 256 x 256) under a 8 192..32 768-row reduction, so filling 256 CUs
+// needs split-K, and every workgroup ends with a 256 KiB f32 partial tile whatever the problem: launched one GEMM at a time
+// that is 64 MiB of partials per launch (as memory-side float atomics at ~1.3 TB/s: 49 us per launch, more than the MFMA
+// work of most of them).  Grouping the weight gradients of one transformer block / resnet into one launch keeps the 256
+// workgroups busy with 3-10 splits per problem, i.e. ONE set of partials per group; the partials leave as plain 16-byte
+// stores (whole-wave 1 KiB lines, ~5 TB/s) into a slab workspace and wgrad_fold_kernel adds the splits into the flat
+// gradient buffer.  Workgroups are dealt out problem-major / K-slice-major in XCD-contiguous order.
+// =====================================================================================================================
+constexpr int PT_WG_MAX = 8;
+struct WgradGroup {
+  GemmParams p[PT_WG_MAX];
+  int wg_end[PT_WG_MAX];         // exclusive end of problem i's run of workgroup ids
+  int nprob;
+  float* slabs;                  // [total workgroups][256 * 256] f32
+};
+static_assert(sizeof(WgradGroup) <= 4096, "kernel argument segment is 4 KiB");
+
+template <int KB>
+__global__ __launch_bounds__(P8_THREADS, 1) void wgrad8p_group_kernel(const WgradGroup g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];
+  const int bid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+  int pid = 0;
+#pragma unroll
+  for (int i = 0; i < PT_WG_MAX - 1; ++i) pid += (i < g.nprob - 1 && bid >= g.wg_end[i]) ? 1 : 0;
+  const int base = pid ? g.wg_end[pid - 1] : 0;
+  gemm8p_body<true, true, 2, 0, KB>(g.p[pid], bid - base, g.slabs + (size_t)bid * (256 * 256), smem);
+}
+
+struct FoldProb { float* C; int64_t ldc, M, N; int tiles_n, ntile, split_k, wg_base; float alpha; int blk_end; };
+struct FoldGroup { FoldProb f[PT_WG_MAX]; int nprob; const float* slabs; };
+
+// C[m][n .. n+3] += alpha * sum over the K-slices of the tile's partials; one thread per 16-byte quad of a tile,
+// 64 blocks of 256 threads per tile; slab reads are fully coalesced (quad-major), gradient rows get 64-byte segments.
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const FoldGroup g) {
+  int pid = 0;
+#pragma unroll
+  for (int i = 0; i < PT_WG_MAX - 1; ++i) pid += (i < g.nprob - 1 && (int)blockIdx.x >= g.f[i].blk_end) ? 1 : 0;
+  const FoldProb& f = g.f[pid];
+  const int lb = blockIdx.x - (pid ? g.f[pid - 1].blk_end : 0);
+  const int tix = lb >> 6, q = ((lb & 63) << 8) + threadIdx.x;          // tile, quad inside the tile (0 .. 16383)
+  const float* src = g.slabs + ((size_t)f.wg_base + tix) * (256 * 256) + (size_t)q * 4;
+  const size_t sstride = (size_t)f.ntile * (256 * 256);
+  f32x4_t s0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int s = 0;
+  for (; s + 1 < f.split_k; s += 2) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + (size_t)s * sstride);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + (size_t)(s + 1) * sstride);
+    s0 += a; s1 += b;
+  }
+  if (s < f.split_k) s0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)s * sstride);
+  s0 += s1;
+  const int lane = q & 63, reg = (q >> 6) & 31, wave = q >> 11;
+  const int tm = tix / f.tiles_n, tn = tix - tm * f.tiles_n;
+  const int64_t m = (int64_t)tm * 256 + (wave >> 2) * 128 + 16 * (reg >> 2) + (lane & 15);
+  const int64_t n = (int64_t)tn * 256 + (wave & 3) * 64 + 16 * (reg & 3) + 4 * (lane >> 4);
+  if (m >= f.M || n >= f.N) return;
+  float* dst = f.C + m * f.ldc + n;
+  if (n + 3 < f.N && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    f32x4_t c = *reinterpret_cast<const f32x4_t*>(dst);
+    c[0] += f.alpha * s0[0]; c[1] += f.alpha * s0[1]; c[2] += f.alpha * s0[2]; c[3] += f.alpha * s0[3];
+    *reinterpret_cast<f32x4_t*>(dst) = c;
+  } else {
+    for (int r = 0; r < 4 && n + r < f.N; ++r) dst[r] += f.alpha * s0[r];
+  }
 }
 
 VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
@@ -851,9 +984,8 @@ int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
   return PT_ERR_ARG;
 }
 
-}  // namespace
-
-extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
+// descriptor checks + conversion shared by pt_gemm and pt_wgrad_group
+static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p) {
   if (!d) return PT_ERR_ARG;
   if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
   const int es = dtype == PT_F32 ? 4 : 2;
@@ -875,7 +1007,6 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
     if (d->C2 && ((reinterpret_cast<uintptr_t>(d->C2) & 15u) || d->ldc2 % 4 != 0)) return PT_ERR_ALIGN;
   }
   // reduction extent must be whole 16-byte chunks when it lies along operand columns
-  GemmParams p;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
   p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
@@ -891,8 +1022,73 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   p.act = d->act; p.act2 = d->act2; p.C2 = reinterpret_cast<char*>(d->C2); p.ldc2 = d->ldc2;
   p.arow_sum = d->arow_sum; p.arow_n = d->arow_n; p.arow_stride = d->arow_stride; p.arow_rep = d->arow_rep > 0 ? d->arow_rep : 1;
   if (p.arow_sum && (d->out_kind != PT_OUT_F32_ATOMIC || d->arow_n <= 0 || d->arow_n > d->M || (p.arow_rep > 1 && d->arow_stride < d->arow_n))) return PT_ERR_ARG;
-  p.tiles_m = p.tiles_n = 0;   // set per tile configuration in launch_bm
+  p.tiles_m = p.tiles_n = 0;   // set per tile configuration at launch
+  return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
+  GemmParams p;
+  const int st = build_params(d, dtype, p);
+  if (st != PT_OK) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);
   return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);
+}
+
+extern "C" int64_t pt_wgrad_group_ws_floats(int target_wgs) {
+  return (int64_t)(target_wgs > 0 ? target_wgs : 256) * 256 * 256;
+}
+
+extern "C" int pt_wgrad_group(const pt_gemm_desc* descs, int n, float* ws, int64_t ws_floats, int target_wgs, pt_stream stream) {
+  if (!descs || n < 1 || n > PT_WG_MAX || !ws || (reinterpret_cast<uintptr_t>(ws) & 15u)) return PT_ERR_ARG;
+  if (target_wgs <= 0) target_wgs = 256;
+  WgradGroup g; FoldGroup fg;
+  int kb = -1;
+  int64_t tiles_total = 0;
+  int nkt[PT_WG_MAX], tiles[PT_WG_MAX];
+  for (int i = 0; i < n; ++i) {
+    const pt_gemm_desc* d = descs + i;
+    const int st = build_params(d, PT_BF16, g.p[i]);
+    if (st != PT_OK) return st;
+    if (d->out_kind != PT_OUT_F32_ATOMIC || !d->A.trans || !d->B.trans || d->conv_wgrad_cin > 0) return PT_ERR_ARG;
+    if (kind_class(d->A.kind) != 0) return PT_ERR_ARG;
+    const int k = kind_class(d->B.kind);
+    if (k == 2 || (kb >= 0 && k != kb)) return PT_ERR_ARG;          // one B operand class per group (plain/concat or conv gather)
+    kb = k;
+    if ((reinterpret_cast<uintptr_t>(d->C) & 3u) != 0) return PT_ERR_ALIGN;
+    g.p[i].tiles_m = (int)((d->M + 255) / 256); g.p[i].tiles_n = (int)((d->N + 255) / 256);
+    tiles[i] = g.p[i].tiles_m * g.p[i].tiles_n;
+    nkt[i] = (int)((d->K + 63) / 64);
+    tiles_total += tiles[i];
+  }
+  if (tiles_total > target_wgs) return PT_ERR_SHAPE;
+  // smallest per-workgroup share w (k-tiles) whose split counts fit the target: every workgroup then has <= w k-tiles
+  auto wgs_for = [&](int w) { int64_t t = 0; for (int i = 0; i < n; ++i) t += (int64_t)tiles[i] * ((nkt[i] + w - 1) / w); return t; };
+  int lo = 1, hi = 1;
+  for (int i = 0; i < n; ++i) hi = nkt[i] > hi ? nkt[i] : hi;
+  while (lo < hi) { const int mid = (lo + hi) / 2; if (wgs_for(mid) <= target_wgs) hi = mid; else lo = mid + 1; }
+  int base = 0, blk = 0;
+  for (int i = 0; i < n; ++i) {
+    int split = (nkt[i] + lo - 1) / lo;
+    const int per = (nkt[i] + split - 1) / split;
+    split = (nkt[i] + per - 1) / per;                                // no empty K-slice: every workgroup writes its slab
+    g.p[i].split_k = split;
+    FoldProb& f = fg.f[i];
+    f.C = reinterpret_cast<float*>(g.p[i].C); f.ldc = g.p[i].ldc; f.M = g.p[i].M; f.N = g.p[i].N;
+    f.tiles_n = g.p[i].tiles_n; f.ntile = tiles[i]; f.split_k = split; f.wg_base = base; f.alpha = g.p[i].alpha;
+    base += tiles[i] * split; blk += tiles[i] * 64;
+    g.wg_end[i] = base; f.blk_end = blk;
+  }
+  for (int i = n; i < PT_WG_MAX; ++i) { g.wg_end[i] = base; fg.f[i] = fg.f[n - 1]; g.p[i] = g.p[n - 1]; }
+  if ((int64_t)base * 256 * 256 > ws_floats) return PT_ERR_ARG;
+  g.nprob = fg.nprob = n; g.slabs = ws; fg.slabs = ws;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (kb == 0) hipLaunchKernelGGL((wgrad8p_group_kernel<0>), dim3((unsigned)base), dim3(P8_THREADS), 0, s, g);
+  else         hipLaunchKernelGGL((wgrad8p_group_kernel<1>), dim3((unsigned)base), dim3(P8_THREADS), 0, s, g);
+  PT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)blk), dim3(256), 0, s, fg);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
 }

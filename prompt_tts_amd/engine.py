@@ -244,10 +244,79 @@ def on_side_stream(fn, *tensors):
 
 
 def join_side_stream(device):
+    flush_wgrads(device)
     cur = torch.cuda.current_stream(device)
     for (dev, _), st in _side.items():
         if dev == device:
             cur.wait_stream(st)
+
+
+# ---- grouped weight gradients ------------------------------------------------------------------------------------------
+# bf16 weight gradients are not launched one by one: they are queued (descriptor + references to dy / x) and go out as ONE
+# pt_wgrad_group launch per <= 8 problems (+ one fold launch) on the side stream -- the weight gradients of a transformer
+# block or of a few resnets.  A weight gradient is a 4..32-tile output under a 8 192..32 768-token reduction: alone it needs
+# 8-64 K-slices to fill the chip and ends in 64 MiB of split-K partials per launch; grouped, the same 256 workgroups carry
+# 3-10 slices per problem and one set of partials per GROUP (csrc/gemm.hip: wgrad8p_group_kernel).  flush_wgrads() is called
+# before a sub-module is announced to the data-parallel reducer and at the end of backward.
+WGRAD_GROUPED = __import__("os").environ.get("PT_WGRAD_GROUPED", "1") != "0"
+WGRAD_GROUP_WGS = int(__import__("os").environ.get("PT_WGRAD_GROUP_WGS", "256"))
+
+
+class _WgradQueue:
+    def __init__(self, device):
+        self.device = device
+        self.lists = {0: [], 1: []}            # B operand class: 0 plain / concat, 1 conv gather
+        self.ws = torch.empty(ops.wgrad_group_ws_floats(WGRAD_GROUP_WGS), dtype=torch.float32, device=device)
+
+    def add(self, cls, desc, tiles, tensors):
+        lst = self.lists[cls]
+        if lst and sum(t for _, t, _ in lst) + tiles > WGRAD_GROUP_WGS:
+            self.flush(cls)
+        lst.append((desc, tiles, tensors))
+        if len(lst) >= ops.WGRAD_GROUP_MAX:
+            self.flush(cls)
+
+    def flush(self, cls=None):
+        for c in ((cls,) if cls is not None else (0, 1)):
+            lst = self.lists[c]
+            if not lst:
+                continue
+            self.lists[c] = []
+            descs = [d for d, _, _ in lst]
+            tensors = [t for _, _, ts in lst for t in ts]
+            on_side_stream(lambda: ops.wgrad_group(descs, self.ws, WGRAD_GROUP_WGS), *tensors)
+
+
+_wq = {}
+
+
+def _wgrad_queue(device):
+    q = _wq.get(device)
+    if q is None:
+        q = _wq[device] = _WgradQueue(device)
+    return q
+
+
+def flush_wgrads(device=None):
+    for dev, q in _wq.items():
+        if device is None or dev == device:
+            q.flush()
+
+
+def _queue_wgrad(cls, M, N, K, A, B, gw, ldc, gbias, tensors):
+    """Queue dW[M][N] += A^T B for the grouped launch; False if this problem must take the single-launch path."""
+    if not WGRAD_GROUPED or _DIAG_SKIP_WGRAD or tensors[0].dtype != torch.bfloat16 or M < 128 or N < 128:
+        return False
+    tiles = math.ceil(M / 256) * math.ceil(N / 256)
+    if tiles > WGRAD_GROUP_WGS:
+        return False
+    kw = {}
+    if gbias is not None:
+        (gb,), n_rep, rstride = _rep(gbias)
+        kw = dict(arow_sum=gb, arow_n=gbias.numel(), arow_rep=n_rep, arow_stride=rstride)
+    desc = ops.gemm_desc(M, N, K, A, B, gw, ldc=ldc, out_kind=L.PT_OUT_F32_ATOMIC, **kw)
+    _wgrad_queue(tensors[0].device).add(cls, desc, tiles, tuple(tensors))   # gw / gb live in the persistent flat buffers
+    return True
 
 
 def _empty(rows, cols, like):
@@ -289,7 +358,8 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
             kw = dict(arow_sum=gb, arow_n=N, arow_rep=n_rep, arow_stride=rstride)
         ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
                  out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype), **kw)
-    on_side_stream(wgrad, dy, x)
+    if not _queue_wgrad(0, N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, gw.stride(0), gbias, (dy, x)):
+        on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
     if (M <= 128 and N >= 2048 and M % 4 == 0 and x.dtype == torch.float32 and dx_out is None and dx_accum is None
@@ -345,7 +415,9 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
         ops.gemm(gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True), ops.conv(x, cin, n_out, n_in, rowmap, trans=True),
                  gw, pt, ldc=3 * cin, out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(gw.shape[0], 3 * cin, Mred, x.dtype),
                  conv_wgrad_cin=cin if padded else 0, conv_wgrad_cin_store=cin_store if padded else 0, **kw)
-    on_side_stream(wgrad, dy, x)
+    if padded or not _queue_wgrad(1, gw.shape[0], 3 * cin, Mred, ops.plain(dy, trans=True),
+                                  ops.conv(x, cin, n_out, n_in, rowmap, trans=True), gw, 3 * cin, gbias, (dy, x)):
+        on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
     if rowmap == L.PT_MAP_UP2:

@@ -83,6 +83,31 @@ def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bi
     check(lib.pt_gemm(C.byref(d), dtype, _stream()), "pt_gemm")
 
 
+def gemm_desc(M, N, K, A, B, out, ldc=None, out_kind=L.PT_OUT_T, split_k=1, alpha=1.0, arow_sum=None, arow_n=0, arow_rep=1,
+              arow_stride=0):
+    """A bare pt_gemm_desc (weight-gradient form) for wgrad_group()."""
+    d = L.pt_gemm_desc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.B = A, B
+    d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
+    d.out_kind = out_kind; d.split_k = split_k; d.alpha = alpha
+    d.arow_sum = _p(arow_sum); d.arow_n = arow_n; d.arow_rep = arow_rep; d.arow_stride = arow_stride
+    return d
+
+
+WGRAD_GROUP_MAX = 8
+
+
+def wgrad_group_ws_floats(target_wgs=256):
+    return int(lib.pt_wgrad_group_ws_floats(target_wgs))
+
+
+def wgrad_group(descs, ws, target_wgs=256):
+    """descs: list of weight-gradient pt_gemm_desc (<= WGRAD_GROUP_MAX, one B operand class); ws: f32 scratch tensor."""
+    arr = (L.pt_gemm_desc * len(descs))(*descs)
+    check(lib.pt_wgrad_group(arr, len(descs), _p(ws), ws.numel(), target_wgs, _stream()), "pt_wgrad_group")
+
+
 def attn_desc(q, k, v, o, lse, B, H, Nq, Nk, D, scale, causal=False, kv_len=None):
     d = L.pt_attn_desc()
     d.B, d.H, d.Nq, d.Nk, d.D = B, H, Nq, Nk, D

@@ -4,9 +4,9 @@ Hot-path row a-9 is the COLLATE: pad/truncate phoneme ids to max_seq_length with
 codes -> float32(float64(code)/1023) -> (x-0.5)/0.5.  It is CPU-side, integer/byte work on tiny arrays and
 runs on the host exactly as in the reference (numpy), producing the same batch dictionary keys.
 
-The text front-end (tts/process_text/*: unidecode + inflect + CMUdict) is out of scope this round (SURVEY 2.1 #9,
-8f-2): SingleSpeakerDataset takes a `text_to_ids` callable (the reference's text_to_sequence fits) or reads
-precomputed `<utt>.cmu.npy` id arrays from the tar.
+Phoneme ids come from the text front-end (prompt_tts_amd/tts/process_text: english_cleaners + CMUdict lookup, as
+tts/dataloader.py:21-22,52-53) unless the tar ships precomputed `<utt>.cmu.npy` id arrays or the caller passes its own
+`text_to_ids` callable; the CMU dictionary FILE is located by process_text.find_cmu_dictionary().
 """
 import io
 import tarfile
@@ -16,6 +16,11 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 BLANK_ID = 148          # len(symbols) in tts/process_text/symbols.py: the interspersed blank (dataloader.py:52-55)
+
+
+def _default_text_to_ids():
+    from .process_text import default_text_to_ids
+    return default_text_to_ids()
 
 
 def intersperse(lst, item):
@@ -79,12 +84,10 @@ class SingleSpeakerDataset(Dataset):
                 text_norm = tf.extractfile(stem + ".normalized.txt").read().decode() if has_norm else text
                 if stem + ".cmu.npy" in names:
                     ids = np.load(io.BytesIO(tf.extractfile(stem + ".cmu.npy").read())).tolist()
-                elif text_to_ids is not None:
-                    ids = list(text_to_ids(text_norm))
                 else:
-                    raise NotImplementedError(
-                        "the CMUdict text front-end is outside this build's scope: pass text_to_ids=... "
-                        "(e.g. the reference's text_to_sequence) or ship <utt>.cmu.npy phoneme ids in the tar")
+                    if text_to_ids is None:
+                        text_to_ids = _default_text_to_ids()       # raises FileNotFoundError if no dictionary is found
+                    ids = list(text_to_ids(text_norm))
                 item = {"code": code / 1023, "text": text, "cmu_sequence": intersperse(ids, BLANK_ID),
                         "code_length": float(tf.extractfile(stem + ".len.txt").read().decode())}
                 if has_norm:
@@ -116,10 +119,8 @@ class LazySingleSpeakerDataset(Dataset):
             for suffix in (".txt", ".len.txt"):
                 if stem + suffix not in self.index:
                     raise KeyError(f"{stem}{suffix} missing from {data_path}")
-            if stem + ".cmu.npy" not in self.index and text_to_ids is None:
-                raise NotImplementedError(
-                    "the CMUdict text front-end is outside this build's scope: pass text_to_ids=... "
-                    "(e.g. the reference's text_to_sequence) or ship <utt>.cmu.npy phoneme ids in the tar")
+            if stem + ".cmu.npy" not in self.index and self.text_to_ids is None:
+                self.text_to_ids = _default_text_to_ids()
 
     def _read(self, name):
         if self._fh is None:                                            # one handle per process (DataLoader workers fork)

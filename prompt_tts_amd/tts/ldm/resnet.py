@@ -104,9 +104,11 @@ class ResnetBlock1D(nn.Module):
         if self.conv_shortcut is not None:
             w, gw = st.w(self.conv_shortcut.weight), st.g(self.conv_shortcut.weight).view(Cout, Cin)
             A = ops.concat(x1, x2, trans=True) if x2 is not None else ops.plain(x1, trans=True)
-            ops.gemm(Cout, Cin, M, ops.plain(dout, trans=True), A, gw, pt, out_kind=L.PT_OUT_F32_ATOMIC,
-                     split_k=E._split_k(Cout, Cin, M, x1.dtype))
-            ops.colsum(dout, st.g(self.conv_shortcut.bias), M, Cout)
+            srcs = (dout, x1) + ((x2,) if x2 is not None else ())
+            if not E._queue_wgrad(0, Cout, Cin, M, ops.plain(dout, trans=True), A, gw, Cin, st.g(self.conv_shortcut.bias), srcs):
+                ops.gemm(Cout, Cin, M, ops.plain(dout, trans=True), A, gw, pt, out_kind=L.PT_OUT_F32_ATOMIC,
+                         split_k=E._split_k(Cout, Cin, M, x1.dtype))
+                ops.colsum(dout, st.g(self.conv_shortcut.bias), M, Cout)
             dres = torch.empty(M, Cin, dtype=x1.dtype, device=x1.device)
             ops.gemm(M, Cin, Cout, ops.plain(dout), ops.plain(w, trans=True), dres, pt)
         else:

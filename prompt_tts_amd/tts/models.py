@@ -207,7 +207,9 @@ class TTSSingleSpeaker(nn.Module):
         hook = None
         if user_hook is not None:
             if getattr(getattr(user_hook, "__self__", None), "joins_side_stream", False):
-                hook = user_hook                  # the reducer orders its own stream after the wgrad stream: no stall here
+                def hook(module):                 # the reducer orders its own stream after the wgrad stream: no stall here;
+                    E.flush_wgrads(st.device)     # queued weight gradients of the announced module go out first
+                    user_hook(module)
             else:
                 def hook(module):                 # weight gradients are produced on the side stream: join it first
                     E.join_side_stream(st.device)

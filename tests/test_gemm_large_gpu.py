@@ -163,3 +163,78 @@ def test_wgrad_conv_large(dev, mode, B, n_in, cin, cout):
              arow_sum=gb, arow_n=cout)
     assert relerr(dw.view(cout, 3, cin), wz.grad) < TOL[dtype]
     assert relerr(gb, dyf.sum(0)) < TOL[dtype]
+
+
+# ---- grouped weight gradients (pt_wgrad_group): one launch for the weight gradients of a transformer block / resnet ---------
+def _ws(dev, target=256):
+    ops, L = _ops()
+    return torch.empty(ops.wgrad_group_ws_floats(target), dtype=torch.float32, device=dev)
+
+
+@pytest.mark.parametrize("target", [256, 64])
+def test_wgrad_group_transformer_block(dev, target):
+    """qkv, out, q (cross), kv (cross, shorter reduction), ff1, ff2 of one BasicTransformerBlock at config B size + one ragged
+    problem, as ONE grouped launch; gradients accumulate on top of existing values; bias gradients ride along."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 7)
+    T, S = 32768, 8192
+    probs = [(T, 1536, 512, False), (T, 512, 512, True), (T, 512, 512, False), (S, 1024, 512, False), (T, 4096, 512, True),
+             (T, 512, 2048, True), (8200, 520, 264, True)]
+    keep, descs, checks = [], [], []
+    for red, nout, kin, has_bias in probs:
+        dy, dyf = rnd((red, nout), dtype, dev, g); x, xf = rnd((red, kin), dtype, dev, g)
+        dw = torch.full((nout, kin), 0.5, dtype=torch.float32, device=dev)
+        gb = torch.zeros(nout, dtype=torch.float32, device=dev) if has_bias else None
+        descs.append(ops.gemm_desc(nout, kin, red, ops.plain(dy, trans=True), ops.plain(x, trans=True), dw,
+                                   out_kind=L.PT_OUT_F32_ATOMIC, arow_sum=gb, arow_n=nout if has_bias else 0))
+        keep.append((dy, x)); checks.append((dw, gb, dyf, xf))
+    ws = _ws(dev, target)
+    if target < 256:
+        with pytest.raises(RuntimeError):                    # more 256 x 256 tiles than workgroups: refused, nothing launched
+            ops.wgrad_group(descs, ws, target)
+        return
+    ops.wgrad_group(descs, ws, target)
+    for dw, gb, dyf, xf in checks:
+        assert relerr(dw - 0.5, dyf.t() @ xf) < TOL[dtype]
+        if gb is not None:
+            assert relerr(gb, dyf.sum(0)) < TOL[dtype]
+    # single-problem groups give the same numbers as the grouped launch (different split counts)
+    dy, x = keep[1]
+    dw1 = torch.zeros(512, 512, dtype=torch.float32, device=dev)
+    ops.wgrad_group([ops.gemm_desc(512, 512, T, ops.plain(dy, trans=True), ops.plain(x, trans=True), dw1,
+                                   out_kind=L.PT_OUT_F32_ATOMIC)], ws)
+    assert relerr(dw1, checks[1][0] - 0.5) < 1e-5
+
+
+def test_wgrad_group_resnet_convs(dev):
+    """conv1 (1024 -> 512, the up-path concat width), conv2, a stride-2 downsampler and an upsample-fused conv: the conv-gather
+    operand class of the grouped kernel (explicit-copies reference through autograd)."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 8)
+    B = 32
+    cases = [("s1", 1024, 1024, 512), ("s1", 1024, 512, 512), ("s2", 1024, 512, 512), ("up2", 512, 512, 512), ("s1", 1000, 264, 520)]
+    descs, checks, keep = [], [], []
+    for mode, n_in, cin, cout in cases:
+        Bc = B if n_in != 1000 else 5
+        n_out = {"s1": n_in, "s2": (n_in - 1) // 2 + 1, "up2": 2 * n_in}[mode]
+        rowmap = {"s1": L.PT_MAP_S1, "s2": L.PT_MAP_S2, "up2": L.PT_MAP_UP2}[mode]
+        x, xf = rnd((Bc * n_in, cin), dtype, dev, g); dy, dyf = rnd((Bc * n_out, cout), dtype, dev, g)
+        wz = torch.zeros(cout, 3, cin, device=dev, requires_grad=True)
+        _conv_ref(xf, wz, Bc, n_in, mode).backward(dyf)
+        dw = torch.zeros(cout, 3 * cin, dtype=torch.float32, device=dev)
+        gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+        descs.append(ops.gemm_desc(cout, 3 * cin, Bc * n_out, ops.plain(dy, trans=True),
+                                   ops.conv(x, cin, n_out, n_in, rowmap, trans=True), dw, ldc=3 * cin,
+                                   out_kind=L.PT_OUT_F32_ATOMIC, arow_sum=gb, arow_n=cout))
+        keep.append((x, dy)); checks.append((dw, gb, wz.grad, dyf, cout, cin))
+    ops.wgrad_group(descs, _ws(dev))
+    for dw, gb, ref, dyf, cout, cin in checks:
+        assert relerr(dw.view(cout, 3, cin), ref) < TOL[dtype]
+        assert relerr(gb, dyf.sum(0)) < TOL[dtype]
+    # one group holds ONE operand class: a plain problem next to conv problems is refused
+    mixed = [descs[0], ops.gemm_desc(512, 512, 1024, ops.plain(keep[1][1], trans=True), ops.plain(keep[1][0], trans=True),
+                                     checks[1][0], out_kind=L.PT_OUT_F32_ATOMIC)]
+    with pytest.raises(RuntimeError):
+        ops.wgrad_group(mixed, _ws(dev))

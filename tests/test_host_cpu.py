@@ -57,7 +57,8 @@ def test_dataset_from_tar_and_loader(tmp_path):
             add(f"{u}.txt", b"hello world"); add(f"{u}.len.txt", b"19.0")
             if u != "c":
                 add(f"{u}.normalized.txt", b"hello world")
-    with pytest.raises(NotImplementedError):
+    os.environ.pop("PT_CMUDICT", None)
+    with pytest.raises(FileNotFoundError):                          # no CMU dictionary file reachable from here: says so
         SingleSpeakerDataset(str(path))
     dl = create_dataloader(str(path), 2, 8, text_to_ids=lambda s: [ord(c) % 147 + 1 for c in s])
     b = next(iter(dl))
@@ -96,7 +97,8 @@ def test_lazy_tar_dataset_equals_in_ram_dataset(tmp_path):
         assert a.keys() == b.keys() and a["text"] == b["text"] and a["cmu_sequence"] == b["cmu_sequence"]
         assert a["code_length"] == b["code_length"] and np.array_equal(a["code"], b["code"])
         assert a.get("text_norm") == b.get("text_norm")
-    with pytest.raises(NotImplementedError):
+    os.environ.pop("PT_CMUDICT", None)
+    with pytest.raises(FileNotFoundError):
         bare = str(tmp_path / "bare.tar"); _ljs_like_tar(bare, with_cmu=False); LazySingleSpeakerDataset(bare)
 
     class FixedT(torch.utils.data.Dataset):                          # codes of one length, as the 12 s windows of the reference
@@ -116,13 +118,13 @@ def test_lazy_tar_dataset_equals_in_ram_dataset(tmp_path):
 
 def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "prompt_tts_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(pt_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(pt_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 27
     from prompt_tts_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert declared - {"pt_abi_version", "pt_status_string", "pt_struct_size"} == set(_lib.SIGNATURES)          # binding == header
+    assert declared - {"pt_abi_version", "pt_status_string", "pt_struct_size", "pt_wgrad_group_ws_floats"} == set(_lib.SIGNATURES)   # binding == header
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (pt_\w+)", out))
     assert exported >= declared
@@ -134,6 +136,7 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.pt_gemm(ctypes.byref(d), 1, None) == -1
     assert _lib.lib.pt_gemm(ctypes.byref(d), 7, None) == -2
     assert _lib.lib.pt_attn_fwd(None, 1, None) == -5
+    assert _lib.lib.pt_wgrad_group(None, 1, None, 0, 0, None) == -5 and _lib.lib.pt_wgrad_group_ws_floats(0) == 256 * 65536
     for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg, _lib.pt_rowconv_desc,
                             _lib.pt_lstm2_desc, _lib.pt_fold_seg)):
         assert _lib.lib.pt_struct_size(i) == ctypes.sizeof(st)          # the ctypes mirror matches the C layout
