@@ -113,10 +113,52 @@ def cpu_baseline(cfg, wl, S, budget_s=20.0):
             "kind": "port", "sample": f"{steps} full training step(s) of the same 1d_config at B={Bc} (f32, {dt:.2f} s/step)"}
 
 
-def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
+def decode_stack_bytes_per_frame(es=2):
+    """Algorithmic HBM bytes of the decode path per code frame (75 frames = one audio second): every layer's input read once
+    and output written once in the activation dtype (es bytes), weights not counted (29.7 MB, read once per batch).
+    RVQ gather 8 codes (int64) -> 128; conv k7 128 -> 512; LSTM input projection 512 -> 2048; LSTM reads 2048 + 512, writes 512;
+    stage (r, cin -> cout): transposed conv cin -> r*cout (twice where the ELU copy is a second output), residual conv3
+    r*cout -> r*cout/2, fused 1x1 + shortcut reads r*cout/2 + r*cout, writes r*cout; final conv k7 32 -> 1 sample (f32 out)."""
+    b = 8 * 8 + 128 * es                       # codes in, code embedding out
+    b += (128 + 512) * es                      # conv0
+    b += (512 + 2048) * es                     # LSTM input projection
+    lstm = (2048 + 512 + 512) * es
+    rows, c = 1, 512
+    for r in (8, 5, 4, 2):
+        cout = c // 2
+        rows_out = rows * r
+        copies = 1 if r * cout <= 64 else 2    # large stages keep a raw + an ELU copy of the upsampled tensor
+        b += rows * c * es + copies * rows_out * cout * es
+        b += rows_out * (cout + cout // 2) * es
+        b += rows_out * (cout // 2 + cout + cout) * es
+        rows, c = rows_out, cout
+    b += rows * 32 * es + rows * 4             # final conv: 32 channels in, one f32 sample out
+    return b, lstm
+
+
+def decode_cpu_baseline(budget_s=15.0):
+    """The CPU oracle (oracle/encodec.decode, plain PyTorch f32) on a bounded sample of the same workload."""
+    from oracle import encodec as oe
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    W = oe.random_weights(0)
+    Bc, Tc = 2, 256
+    codes = torch.randint(0, 1024, (Bc, 8, Tc), generator=torch.Generator().manual_seed(7))
+    t0 = time.time(); oe.decode(codes, W); warm = time.time() - t0
+    reps = max(1, min(4, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(reps):
+        oe.decode(codes, W)
+    dt = (time.time() - t0) / reps
+    return {"value": Bc * Tc / 75.0 / dt, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} decode(s) of {Bc} x {Tc} frames with the CPU oracle (f32, {dt:.2f} s each; the LSTM is sequential in T)"}
+
+
+def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=True):
     """BASELINE configs[3] second half: Encodec 24 kHz decode of `prompts` x T frames -> generated-audio-seconds/s."""
     from decode_codec import random_decoder_weights
     from prompt_tts_amd.encodec import EncodecDecoder
+    from prompt_tts_amd import ops as _ops
     dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=dtype)
     codes = torch.randint(0, 1024, (prompts, 8, T), generator=torch.Generator().manual_seed(7)).to(dev)
     dec.decode(codes); torch.cuda.synchronize()
@@ -128,6 +170,17 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
     ms = e0.elapsed_time(e1) / iters
     audio_s = prompts * T / 75.0
     flops = 2 * 19863552 * prompts * T                     # 19.86 M MAC per frame
+    # where the time goes (HIP events around every C-ABI call of one extra decode): the LSTM recurrence is latency-bound
+    # (reported as steps/s), everything else is the conv stack, HBM-bound -> GB/s against the 8 TB/s roofline
+    per = _ops.profile_one_step(lambda: dec.decode(codes))
+    lstm_ms = per.get("pt_lstm2_forward", {}).get("ms_total", 0.0)
+    stack_ms = sum(v["ms_total"] for k, v in per.items() if k != "pt_lstm2_forward")
+    stack_b, lstm_b = decode_stack_bytes_per_frame(2 if dtype == torch.bfloat16 else 4)
+    stack_bytes = stack_b * prompts * T
+    hbm = {"bound": "hbm", "kernel": "Encodec decoder conv stack (pt_gemm / pt_rowconv / pt_rvq_decode launches of one batch)",
+           "achieved": stack_bytes / (stack_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+           "frac": stack_bytes / (stack_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_frame": stack_b, "ms": stack_ms,
+           "traffic": None, "note": "algorithmic bytes = each layer's input read once + output written once (bf16), weights excluded"}
     # token stage of configs[3] (build-defined ops, SURVEY 8a'): RVQ-codebook logits head Linear(d -> n_q * 1024) on (B, T, d)
     # hidden states, then greedy / top-k = 32 sampling per (prompt, codebook, frame) with injected uniforms
     from prompt_tts_amd import engine as E, ops
@@ -150,18 +203,22 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16):
         e1.record(); torch.cuda.synchronize()
         stage_ms[k] = e0.elapsed_time(e1) / iters
     assert sampled.shape == codes.shape and int(sampled.min()) >= 0 and int(sampled.max()) < bins
-    return {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
-            "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
-            "lstm_steps_per_s": 2 * T / (ms * 1e-3), "achieved_tflops": flops / (ms * 1e-3) / 1e12,
-            "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
-            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
-            "weights": "seeded random (no checkpoint offline)"}
+    out = {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
+           "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+           "lstm_ms": lstm_ms, "lstm_steps_per_s": 2 * T / (lstm_ms * 1e-3) if lstm_ms else None,
+           "achieved_tflops": flops / (ms * 1e-3) / 1e12, "roofline": hbm,
+           "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
+           "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
+           "weights": "seeded random (no checkpoint offline)"}
+    if cpu:
+        out["cpu_baseline"] = decode_cpu_baseline()
+    return out
 
 
 def encode_bench(dev, prompts=32, seconds=12, iters=3):
     """Encodec ENCODE leg (generate_code.py defaults: batch 32, 12 s windows at 24 kHz -> 900 frames), f32, seeded weights."""
     import encode_codec
-    enc = encode_codec.load_encoder(None, torch.float32, dev)
+    enc = encode_codec.load_encoder(None, torch.float32, dev, random_weights=True)
     wav = (torch.randn(prompts, 1, 24000 * seconds, generator=torch.Generator().manual_seed(7)) * 0.3).to(dev)
     enc.encode(wav); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -291,47 +348,64 @@ def main():
     }
     note(f"timed {args.steps} steps: {wall / args.steps * 1e3:.1f} ms/step")
     if rank == 0 and world == 1:
-        # per-symbol device times of ONE extra step (HIP events around every C-ABI call on the launch stream); the
-        # dominant symbol's average is what profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats) must agree with.
-        # "roofline" = that dominant kernel (per launch); "roofline_step" = the aggregate of all launches of one step
+        # per-class device times of ONE extra step (HIP events around every C-ABI call, recorded on the stream the call is
+        # launched on: the weight gradients run on the side stream); the dominant class's average is what the committed
+        # profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command) must agree with.
+        # "roofline" = the GEMM class with the largest share of the step (per launch); "roofline_wgrad" = the grouped weight-
+        # gradient kernel (the kernel the round-1 review named); "roofline_step" = the aggregate of all launches of one step
         captured = []
         kern = ops.profile_one_step(step, capture=captured)
-        mf = {k: v for k, v in kern.items() if "tflops" in v and k.startswith("gemm<" + args.dtype)}
-        # HBM-side bytes come from the committed rocprofv3 PMC passes of this same command (profiles/, see tools/rocprof_summary.py)
+        mf = {k: v for k, v in kern.items() if "tflops" in v and (k.startswith("gemm<" + args.dtype) or k.startswith("wgrad_group"))}
         pmc = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if args.workload == "B" and args.dtype == "bf16" and not args.batch and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            out["roofline"]["traffic"] = pmc["step_bytes"]
-            out["roofline"]["traffic_note"] = "HBM-side bytes of one step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_traffic.json)"
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            if args.workload == "B" and args.dtype == "bf16" and not args.batch and os.path.exists(os.path.join(prof_dir, cand)):
+                with open(os.path.join(prof_dir, cand)) as f:
+                    pmc = json.load(f)
+                out["roofline"]["traffic"] = pmc["step_bytes"]
+                out["roofline"]["traffic_note"] = f"HBM-side bytes of one step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/{cand})"
+                break
+        SYMBOL = {   # label -> kernel symbol(s) in the rocprofv3 summaries
+            "wgrad_group<bf16>/plain": "wgrad8p_group_kernel<0>", "wgrad_group<bf16>/conv": "wgrad8p_group_kernel<1>",
+            "gemm<bf16,NN,store>/plain": "gemm8p_kernel<false, false, false, 0, 0> (>= 192 tiles of 256x256) / gemm_kernel<bf16_t, false, false, false, 0, 0, 128, 128>",
+            "gemm<bf16,NT,store>/plain": "gemm8p_kernel<false, true, false, 0, 0> (>= 192 tiles of 256x256) / gemm_kernel<bf16_t, false, true, false, 0, 0, 128, 128>",
+            "gemm<bf16,NN,store>/conv": "gemm8p_kernel<false, false, false, 1, 0> / gemm_kernel<bf16_t, false, false, false, 1, 0, 128, 128>",
+            "gemm<bf16,NT,store>/conv": "gemm8p_kernel<false, true, false, 1, 2> / gemm_kernel<bf16_t, false, true, false, 1, 2, 128, 128>"}
+
+        def kernel_roofline(name, note):
+            r = {"kernel": name, "symbol": SYMBOL.get(name, name), "bound": "mfma", "calls_per_step": mf[name]["calls"],
+                 "avg_us": mf[name]["ms_avg"] * 1e3, "algorithmic_gflop_per_launch": mf[name]["gflop_avg"],
+                 "achieved": mf[name]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "traffic": None,
+                 "share_of_step": mf[name]["ms_total"] / (step_s * 1e3), "note": note}
+            if pmc is not None:
+                sym = SYMBOL.get(name, name).split(" ")[0]
+                hit = [k for k in pmc["kernels"] if sym in k["kernel"]]
+                r["traffic"] = hit[0]["bytes_per_launch"] if hit else None
+            calls, iso_us, iso_tf = ops.replay_captured(captured, name)
+            r["isolated"] = {"calls": calls, "avg_us": iso_us, "achieved": iso_tf, "frac": iso_tf / peak,
+                             "note": "the same launches of one step replayed back to back, alone on the chip"}
+            return r
         if mf:
-            name = max(mf, key=lambda k: mf[k]["ms_total"])
-            ta, tb = name.split(",")[1]
-            tpl = f"{'true' if ta == 'T' else 'false'}, {'true' if tb == 'T' else 'false'}, {'true' if 'atomic' in name else 'false'}"
-            el = "bf16_t" if args.dtype == "bf16" else "float"
-            symbol = f"gemm_kernel<{el}, {tpl}, 0, {1 if name.endswith('/conv') else 0}, 128, 128>"
-            traffic = None
-            if pmc is not None and "atomic" in name:            # the wgrads run on the two-stage kernel only: one symbol
-                hit = [k for k in pmc["kernels"] if symbol in k["kernel"]]
-                traffic = hit[0]["bytes_per_launch"] if hit else None
             out["roofline_step"] = out["roofline"]          # the aggregate MFMA roofline of the whole step stays available
-            out["roofline"] = {
-                "kernel": name, "symbol": symbol if "atomic" in name else symbol + " / gemm8p_kernel<...> (tile chosen per shape)",
-                "bound": "mfma", "calls_per_step": mf[name]["calls"], "avg_us": mf[name]["ms_avg"] * 1e3,
-                "algorithmic_gflop_per_launch": mf[name]["gflop_avg"], "achieved": mf[name]["tflops"], "peak": peak,
-                "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "traffic": traffic,
-                "share_of_step": mf[name]["ms_total"] / (step_s * 1e3),
-                "note": "averaged over all launches of one step, measured while the dgrad chain runs beside it on the main stream"}
-            calls, iso_us, iso_tf = ops.replay_gemms(captured, name)
-            out["roofline"]["isolated"] = {"calls": calls, "avg_us": iso_us, "achieved": iso_tf, "frac": iso_tf / peak,
-                                           "note": "the same launches of one step replayed back to back, alone on the chip"}
+            name = max(mf, key=lambda k: mf[k]["ms_total"])
+            out["roofline"] = kernel_roofline(name, "averaged over all launches of one step, while the other stream's kernels share the chip")
+            wg = [k for k in mf if k.startswith("wgrad_group")]
+            if wg:
+                tot_ms = sum(mf[k]["ms_total"] for k in wg); tot_fl = sum(mf[k]["gflop_avg"] * mf[k]["calls"] for k in wg)
+                iso = [ops.replay_captured(captured, k) for k in wg]
+                iso_ms = sum(c * us for c, us, _ in iso) / 1e3
+                out["roofline_wgrad"] = {
+                    "kernel": "grouped weight gradients (wgrad8p_group_kernel<0|1> + wgrad_fold_kernel)", "bound": "mfma",
+                    "launches_per_step": sum(mf[k]["calls"] for k in wg), "ms_per_step": tot_ms, "algorithmic_gflop_per_step": tot_fl,
+                    "achieved": tot_fl / tot_ms, "peak": peak, "unit": "TFLOP/s", "frac": tot_fl / tot_ms / peak,
+                    "isolated": {"ms_per_step": iso_ms, "achieved": tot_fl / iso_ms, "frac": tot_fl / iso_ms / peak},
+                    "round1": {"symbol": "gemm_kernel<bf16_t, true, true, true, 0, 0|1, 128, 128>", "frac": 0.106, "isolated_frac": 0.136}}
             del captured
         if args.kernel_timing:
             out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_decode:
         note("decode leg (configs[3]: 64 prompts x 1024 frames)")
-        out["decode"] = decode_bench(dev)
+        out["decode"] = decode_bench(dev, cpu=not args.no_cpu_baseline)
         note("encode leg (32 waveforms x 12 s)")
         out["encode"] = encode_bench(dev)
         note("sampling leg (reverse diffusion with the training model)")

@@ -5,7 +5,8 @@
 
 The reference builds `EncodecModel.encodec_model_24khz()` at import time, which downloads pretrained weights;
 this build never fetches anything: pass `--weights <encodec state_dict .pt>` (original `encodec` package naming,
-weight_g/weight_v are folded on load).  Without it a seeded random decoder is used (useful only for plumbing).
+weight_g/weight_v are folded on load).  A seeded RANDOM decoder (noise out; plumbing and benchmarks only) is used only when
+asked for explicitly: `--random_weights` / `load_decoder(None, random_weights=True)`.
 """
 from argparse import ArgumentParser
 
@@ -17,12 +18,15 @@ from prompt_tts_amd.encodec import EncodecDecoder, weights_from_encodec_state_di
 _model = None
 
 
-def load_decoder(weights_path=None, dtype=torch.bfloat16, device="cuda", seed=0):
+def load_decoder(weights_path=None, dtype=torch.bfloat16, device="cuda", seed=0, random_weights=False):
     global _model
     if weights_path is not None:
         W = weights_from_encodec_state_dict(torch.load(weights_path, map_location="cpu"))
-    else:
+    elif random_weights:
         W = random_decoder_weights(seed)
+    else:
+        raise RuntimeError("no Encodec weights: pass --weights / load_decoder(<encodec state_dict .pt>) -- the pretrained 24 kHz "
+                           "model the reference downloads is never fetched here (random_weights=True gives a seeded random decoder)")
     _model = EncodecDecoder(W, device=device, dtype=dtype)
     return _model
 
@@ -53,8 +57,10 @@ def random_decoder_weights(seed=0, n_q=8):
 def decode(encoded_frames: torch.Tensor):
     if len(encoded_frames.shape) != 3:
         raise BaseException("The encoded_frames must have the shape of [B, N_q, T]")
-    model = _model if _model is not None else load_decoder()
-    return model.decode(encoded_frames)
+    if _model is None:
+        raise RuntimeError("decode(): no decoder loaded -- call load_decoder(<encodec state_dict .pt>) first (the reference downloads "
+                           "pretrained weights at import time; this build never fetches anything)")
+    return _model.decode(encoded_frames)
 
 
 def write_wav(path, wav, sample_rate=EncodecDecoder.sample_rate):
@@ -64,12 +70,12 @@ def write_wav(path, wav, sample_rate=EncodecDecoder.sample_rate):
     wavfile.write(path, sample_rate, (mono * 32767.0).astype(np.int16))
 
 
-def run_cli(npy_path, weights=None, dtype="bf16"):
+def run_cli(npy_path, weights=None, dtype="bf16", random_weights=False):
     """`--npy_path x.npy` -> x.wav (first item of the batch), as the reference's command line does."""
     codes = torch.from_numpy(np.load(npy_path))
     if codes.dim() == 2:                          # a single utterance saved as [N_q, T]
         codes = codes[None]
-    load_decoder(weights, {"f32": torch.float32, "bf16": torch.bfloat16}[dtype])
+    load_decoder(weights, {"f32": torch.float32, "bf16": torch.bfloat16}[dtype], random_weights=random_weights)
     wav = decode(codes)
     out_path = npy_path[:-4] + ".wav" if npy_path.endswith(".npy") else npy_path + ".wav"
     write_wav(out_path, wav[0])
@@ -79,7 +85,10 @@ def run_cli(npy_path, weights=None, dtype="bf16"):
 if __name__ == "__main__":
     cli = ArgumentParser(description="Codec codes (.npy, [N_q, T] or [B, N_q, T]) -> 24 kHz waveform next to the input file.")
     cli.add_argument("--npy_path", required=True, help="codec code matrix written by the data preparation")
-    cli.add_argument("--weights", default=None, help="encodec state_dict (.pt); a seeded random decoder if omitted")
+    cli.add_argument("--weights", default=None, help="encodec state_dict (.pt) in the original package's naming")
+    cli.add_argument("--random_weights", action="store_true", help="seeded random decoder (writes noise: plumbing tests only)")
     cli.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ns = cli.parse_args()
-    print(run_cli(ns.npy_path, ns.weights, ns.dtype))
+    if ns.weights is None and not ns.random_weights:
+        cli.error("--weights <encodec state_dict .pt> is required (or --random_weights for a plumbing run)")
+    print(run_cli(ns.npy_path, ns.weights, ns.dtype, ns.random_weights))

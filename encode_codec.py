@@ -5,11 +5,15 @@
 (prompt_tts_amd/encodec.py: EncodecEncoder).
 
 The reference builds `EncodecModel.encodec_model_24khz()` at import time (downloads pretrained weights) and reads audio with
-torchaudio; this build never fetches anything and has no torchaudio: pass `--weights <encodec state_dict .pt>` (original
-`encodec` package naming; weight_g / weight_v are folded on load; a seeded random encoder otherwise, useful only for plumbing)
-and 24 kHz PCM-16 WAV members (read with the stdlib `wave` module; stereo keeps its first channel as the reference does).
+torchaudio + encodec.utils.convert_audio; this build never fetches anything and has neither package: pass
+`--weights <encodec state_dict .pt>` (original `encodec` package naming; weight_g / weight_v are folded on load; a seeded RANDOM
+encoder only with an explicit `--random_weights`).  Audio members are PCM WAV files of any sample rate, 8/16/24/32-bit, read
+with the stdlib `wave` module: stereo keeps its first channel (generate_code.py:26-27) and other rates are resampled to 24 kHz
+with a windowed-sinc kernel (torchaudio.transforms.Resample defaults, which convert_audio applies: Hann window,
+lowpass_filter_width 6, rolloff 0.99) -- host-side, once per file, like the reference.
 """
 import io
+import math
 import tarfile
 import wave
 from argparse import ArgumentParser
@@ -46,25 +50,63 @@ def random_encoder_weights(seed=1, n_q=8):
     return W
 
 
-def load_encoder(weights_path=None, dtype=torch.float32, device="cuda", seed=1):
+def load_encoder(weights_path=None, dtype=torch.float32, device="cuda", seed=1, random_weights=False):
     global _model
     if weights_path is not None:
         W = encoder_weights_from_encodec_state_dict(torch.load(weights_path, map_location="cpu"))
-    else:
+    elif random_weights:
         W = random_encoder_weights(seed)
+    else:
+        raise RuntimeError("no Encodec weights: pass --weights / load_encoder(<encodec state_dict .pt>); codes from a random encoder "
+                           "would silently become training data (random_weights=True for plumbing runs)")
     _model = EncodecEncoder(W, device=device, dtype=dtype)
     return _model
 
 
-def read_wav(fileobj):
-    """24 kHz PCM-16 WAV -> float tensor (1, n) in [-1, 1) (first channel of a stereo file, generate_code.py:27-28)."""
+def resample(wav, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """(channels, n) float -> (channels, ceil(n * new / orig)): band-limited sinc interpolation with a Hann window, the
+    algorithm and defaults of torchaudio.transforms.Resample (what encodec.utils.convert_audio applies, generate_code.py:28).
+    torchaudio is not installed here: parity unpinned, checked by known answers (tests/test_host_cpu.py)."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return wav
+    g = math.gcd(orig_freq, new_freq)
+    o, n = orig_freq // g, new_freq // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = (torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx) * base
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)        # (n, 1, 2 width + o)
+    length = wav.shape[-1]
+    x = torch.nn.functional.pad(wav.reshape(-1, length).double(), (width, width + o))
+    y = torch.nn.functional.conv1d(x[:, None], kernel, stride=o)                               # (channels, n, frames)
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)[:, :int(math.ceil(n * length / o))]
+    return y.to(wav.dtype).reshape(wav.shape[:-1] + (-1,))
+
+
+def read_wav(fileobj, target_rate=SAMPLE_RATE):
+    """PCM WAV -> float tensor (1, n) in [-1, 1) at 24 kHz: first channel of a multi-channel file (generate_code.py:26-27),
+    resampled when the file's rate differs (generate_code.py:28)."""
     with wave.open(fileobj, "rb") as w:
-        if w.getframerate() != SAMPLE_RATE or w.getsampwidth() != 2:
-            raise ValueError(f"expected {SAMPLE_RATE} Hz PCM-16 audio (no resampler in this build), got "
-                             f"{w.getframerate()} Hz / {8 * w.getsampwidth()} bit")
-        ch = w.getnchannels()
-        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, ch)[:, 0]
-    return torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None, :]
+        width, ch, rate = w.getsampwidth(), w.getnchannels(), w.getframerate()
+        raw = w.readframes(w.getnframes())
+    if width == 1:
+        pcm = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif width == 2:
+        pcm = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        pcm = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif width == 4:
+        pcm = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:
+        raise ValueError(f"unsupported PCM sample width {width} bytes")
+    mono = torch.from_numpy(np.ascontiguousarray(pcm.reshape(-1, ch)[:, 0]))[None, :]
+    return resample(mono, rate, target_rate)
 
 
 def create_batch(members, tf, batch_size, max_duration):
@@ -91,9 +133,10 @@ def create_batch(members, tf, batch_size, max_duration):
 
 def generate(batch):
     """list of (1, 1, L) waveforms -> numpy int64 codes (B, 8, L/320) (generate_code.py:45-51)."""
-    model = _model if _model is not None else load_encoder()
+    if _model is None:
+        raise RuntimeError("generate(): no encoder loaded -- call load_encoder(<encodec state_dict .pt>) first")
     wav = torch.cat(batch)
-    return model.encode(wav).cpu().numpy()
+    return _model.encode(wav).cpu().numpy()
 
 
 def _add_bytes(tar, name, payload):
@@ -123,11 +166,14 @@ def main(input_file, batch_size, max_duration):
 
 if __name__ == "__main__":
     cli = ArgumentParser(description="Waveforms -> Encodec codes (WebDataset-style tar in, tar out).")
-    cli.add_argument("--input_file", type=str, required=True, help="tar with 24 kHz PCM-16 .wav members (+ .txt transcripts)")
+    cli.add_argument("--input_file", type=str, required=True, help="tar with PCM .wav members of any sample rate (+ .txt transcripts)")
     cli.add_argument("--batch_size", type=int, default=32, help="waveforms per encode call")
     cli.add_argument("--max_duration", type=int, default=12, help="seconds every waveform is zero-padded to")
-    cli.add_argument("--weights", type=str, default=None, help="encodec state_dict (.pt); seeded random weights otherwise")
+    cli.add_argument("--weights", type=str, default=None, help="encodec state_dict (.pt) in the original package's naming")
+    cli.add_argument("--random_weights", action="store_true", help="seeded random encoder (meaningless codes: plumbing tests only)")
     cli.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ns = cli.parse_args()
-    load_encoder(ns.weights, torch.float32 if ns.dtype == "f32" else torch.bfloat16)
+    if ns.weights is None and not ns.random_weights:
+        cli.error("--weights <encodec state_dict .pt> is required (or --random_weights for a plumbing run)")
+    load_encoder(ns.weights, torch.float32 if ns.dtype == "f32" else torch.bfloat16, random_weights=ns.random_weights)
     print(main(ns.input_file, ns.batch_size, ns.max_duration))

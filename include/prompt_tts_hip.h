@@ -88,13 +88,23 @@ typedef struct pt_gemm_desc {
   int32_t conv_wgrad_cin;        /* > 0 (padded-Cin conv wgrad): C index (m, n=tap*cin+ci) -> (m*3 + tap)*cin_store + ci, ci >= cin_store dropped */
   int32_t conv_wgrad_cin_store;  /* real Cin of the stored [Cout][3][Cin] gradient                 */
   float alpha;                   /* scales the accumulator before the epilogue adds               */
-  int32_t act;                   /* 0 none, 1 ELU(alpha=1) applied to what is stored in C         */
+  int32_t act;                   /* 0 none, 1 ELU(alpha=1) applied to what is stored in C;
+                                    2 GEGLU forward (bf16; diffusers FeedForward GEGLU): the N = 2F output columns are in the
+                                      INTERLEAVED order (column 64q+t: t < 32 value 32q+t, else gate F+32q+t-32 -- the order of
+                                      the weight shadow rows); C gets the raw projection, C2[m][32q+t] = value * gelu_erf(gate)
+                                      (ldc2 >= F); bias is indexed in the ORIGINAL order;
+                                    3 GEGLU backward fused into the following Linear's dgrad: the tile is d(act)[M][N = F],
+                                      `residual` = the saved interleaved projection [M][>= 2F], C = d(projection) [M][ldc >= 2F],
+                                      interleaved.  2 and 3 need M, N multiples of 256 and 16-byte aligned rows              */
   int32_t act2;                  /* same for the optional second output                            */
   void* C2; int64_t ldc2;        /* optional second store of the same tile (e.g. raw + ELU), or NULL */
   float* arow_sum;               /* PT_OUT_F32_ATOMIC only, or NULL: arow_sum[m] += alpha * sum_k VA(m,k) for m < arow_n -- the bias
                                     gradient (column sums of dy) rides on the wgrad GEMM as one extra all-ones MFMA column, in
                                     the workgroups of the first tile column; replicated destination like pt_colsum           */
   int64_t arow_n; int64_t arow_stride; int32_t arow_rep; int32_t _pad2;
+  int64_t geglu_rows;            /* pt_wgrad_group only, or 0: F > 0 = the M = 2F rows of this weight gradient are in the
+                                    interleaved order of act = 2 (A = d(projection) as written by act = 3); C and arow_sum are
+                                    written in the ORIGINAL row order                                                       */
 } pt_gemm_desc;
 
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
@@ -189,9 +199,12 @@ int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float
                      int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int accumulate_dx2,
                      float raw_eps, int ws_zeroed, int n_rep, int64_t rep_stride, int dtype, pt_stream stream);
 
-/* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F]. */
-int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream);
-int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int dtype, pt_stream stream);
+/* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F].
+ * `bias` (f32 [2F] in the ORIGINAL column order, or NULL) is first added to proj in place.  interleaved != 0: proj / dproj
+ * columns are in the interleaved order of pt_gemm act 2 / 3 (value of j at 64(j/32) + j%32, its gate 32 further): the
+ * stand-alone form of those fused epilogues, for row counts they do not take. */
+int pt_geglu_fwd(void* proj, const float* bias, void* out, int64_t M, int64_t F, int interleaved, int dtype, pt_stream stream);
+int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int interleaved, int dtype, pt_stream stream);
 
 /* SiLU on a flat f32/bf16 vector (time-embedding MLP, resnet.py:255-261). */
 int pt_silu_fwd(const void* x, void* y, int64_t n, int dtype, pt_stream stream);
@@ -244,8 +257,9 @@ typedef struct pt_param_seg {
   int64_t offset;        /* element offset in the flat master / grad / m / v buffers            */
   int64_t numel;
   int64_t shadow_offset; /* element offset in the shadow buffer                                 */
-  int32_t layout;        /* 0: copy; 1: Conv1d (Cout,Cin,3) -> shadow [Cout][3][cin_pad]          */
-  int32_t cin;           /* layout 1: Cin                                                        */
+  int32_t layout;        /* 0: copy; 1: Conv1d (Cout,Cin,3) -> shadow [Cout][3][cin_pad]; 2: GEGLU projection weight [2F][cin]
+                            -> shadow rows interleaved (value row 32q+t at 64q+t, gate row F+32q+t at 64q+32+t), see pt_gemm act 2 */
+  int32_t cin;           /* layout 1: Cin; layout 2: columns of the weight                        */
   int32_t cin_pad;       /* layout 1: padded Cin of the shadow (>= cin, multiple of 8)           */
   int32_t frozen;        /* 1: never updated (unused parameters: Transformer1DModel.proj_out)    */
 } pt_param_seg;

@@ -31,7 +31,7 @@ class pt_gemm_desc(C.Structure):
                 ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
                 ("C2", C.c_void_p), ("ldc2", C.c_int64),
                 ("arow_sum", C.c_void_p), ("arow_n", C.c_int64), ("arow_stride", C.c_int64), ("arow_rep", C.c_int32),
-                ("_pad2", C.c_int32)]
+                ("_pad2", C.c_int32), ("geglu_rows", C.c_int64)]
 
 
 class pt_attn_desc(C.Structure):
@@ -83,8 +83,8 @@ SIGNATURES = {
     "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _i32, _vp],
     "pt_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i64, _i32, _vp],
-    "pt_geglu_fwd": [_vp, _vp, _i64, _i64, _i32, _vp],
-    "pt_geglu_bwd": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pt_geglu_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "pt_geglu_bwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "pt_silu_fwd": [_vp, _vp, _i64, _i32, _vp],
     "pt_silu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_add": [_vp, _vp, _vp, _i64, _i32, _vp],

@@ -1,0 +1,122 @@
+"""Checkpoint files of the training loop (reference: train.py:139-144) and the resume the reference never wrote.
+
+Per saved epoch N the reference writes, into `ckpt_dir` (path and name concatenated without a separator):
+  ckpt_N.pt    model.state_dict()                               -- same keys / shapes here
+  optim_N.pt   torch.optim.AdamW(model.parameters()).state_dict() -- written here in exactly that format:
+               {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{lr, betas, eps, weight_decay, ..., "params"}]}
+               with i = position in model.parameters(); the never-used proj_out parameters have no state entry (their
+               .grad is None under the reference too), so torch.optim.AdamW(...).load_state_dict() accepts the file.
+  (accelerator.save_state: RNG / scheduler state)  -- here resume_N.pt: optimizer-step counters and each rank's noise generator.
+
+Saving does not stall the step loop: tensors are snapshotted device -> pinned host memory on a copy stream (ordered after the
+optimizer step that produced them) and a background thread serialises them; wait() joins before the next save / at exit.
+"""
+import os
+import threading
+
+import torch
+
+
+def adamw_state_dict(store, lr, hyper):
+    """torch.optim.AdamW.state_dict() for the flat store: per-parameter views of the flat Adam moments."""
+    state, ids = {}, []
+    step = torch.tensor(float(store.step_count))
+    for i, p in enumerate(store.params_in_model_order()):
+        ids.append(i)
+        info = store.info[id(p)]
+        if info["frozen"] or store.adam_m is None:
+            continue
+        lo, hi = info["off"], info["off"] + info["n"]
+        state[i] = {"step": step.clone(), "exp_avg": store.adam_m[lo:hi].view(p.shape), "exp_avg_sq": store.adam_v[lo:hi].view(p.shape)}
+    group = {"lr": lr, "betas": tuple(hyper["betas"]), "eps": hyper["eps"], "weight_decay": hyper["weight_decay"], "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "initial_lr": hyper["lr"], "params": ids}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_adamw_state_dict(store, sd):
+    """Inverse of adamw_state_dict (also accepts the flat private format written by round-1 builds)."""
+    dev = store.device
+    if "exp_avg" in sd and "names" in sd:                                   # round-1 flat format
+        if sd["names"] != store.names:
+            raise RuntimeError("optimizer checkpoint does not match this model's parameter list")
+        store.adam_m = sd["exp_avg"].to(dev).clone(); store.adam_v = sd["exp_avg_sq"].to(dev).clone()
+        store.step_count = int(sd["step"])
+        return
+    params = store.params_in_model_order()
+    ids = sd["param_groups"][0]["params"]
+    if len(ids) != len(params):
+        raise RuntimeError(f"optimizer checkpoint holds {len(ids)} parameters, the model has {len(params)}")
+    store.adam_m = torch.zeros_like(store.flat_p); store.adam_v = torch.zeros_like(store.flat_p)
+    steps = set()
+    for i, p in zip(ids, params):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        info = store.info[id(p)]
+        if tuple(st["exp_avg"].shape) != tuple(p.shape):
+            raise RuntimeError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {info['name']} {tuple(p.shape)}")
+        lo, hi = info["off"], info["off"] + info["n"]
+        store.adam_m[lo:hi].view(p.shape).copy_(st["exp_avg"].to(dev))
+        store.adam_v[lo:hi].view(p.shape).copy_(st["exp_avg_sq"].to(dev))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise RuntimeError(f"per-parameter step counts differ ({sorted(steps)}): not a checkpoint of this training loop")
+    store.step_count = steps.pop() if steps else 0
+
+
+class AsyncCheckpointWriter:
+    """save(path, obj): snapshot every tensor in the (nested dict / list) `obj` to pinned host memory on a copy stream, then
+    torch.save it from a background thread to `path` (written as path + '.tmp', renamed when complete)."""
+
+    def __init__(self, device=None):
+        self.device = torch.device(device) if device is not None else None
+        self.stream = torch.cuda.Stream(device=self.device) if self.device is not None and self.device.type == "cuda" else None
+        self._threads = []
+        self.errors = []
+
+    def _snapshot(self, obj):
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                host = torch.empty(obj.shape, dtype=obj.dtype, device="cpu", pin_memory=True)
+                host.copy_(obj, non_blocking=True)
+                return host
+            return obj.detach().clone()
+        if isinstance(obj, dict):
+            return type(obj)((k, self._snapshot(v)) for k, v in obj.items())
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._snapshot(v) for v in obj)
+        return obj
+
+    def save(self, path, obj):
+        done = None
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))     # after the step that produced the tensors
+            with torch.cuda.stream(self.stream):
+                snap = self._snapshot(obj)
+                done = torch.cuda.Event(); done.record(self.stream)
+            # the device tensors must stay untouched until the copies ran: the caller's stream waits for the copy stream
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        else:
+            snap = self._snapshot(obj)
+
+        def work():
+            try:
+                if done is not None:
+                    done.synchronize()
+                tmp = path + ".tmp"
+                torch.save(snap, tmp)
+                os.replace(tmp, path)
+            except BaseException as e:          # surfaced by wait()
+                self.errors.append(e)
+        th = threading.Thread(target=work, daemon=False)
+        th.start()
+        self._threads.append(th)
+
+    def wait(self):
+        for th in self._threads:
+            th.join()
+        self._threads = []
+        if self.errors:
+            e = self.errors[0]; self.errors = []
+            raise e

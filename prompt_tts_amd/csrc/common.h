@@ -108,6 +108,19 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// erf-GELU and its derivative from ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7), and
+// exp(-(x/sqrt 2)^2) = exp(-x^2/2) is also the Gaussian density the derivative needs.  Used by the GEGLU epilogues of the
+// bf16 GEMMs, where a library erff per element would cost more VALU time than the tile's MFMAs.
+__device__ __forceinline__ void gelu_erf_fast(float x, float& gelu, float& dgelu) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, x));
+  gelu = x * cdf;
+  dgelu = cdf + x * 0.39894228040143267794f * e;
+}
+
 // host-side launch check
 #define PT_LAUNCH_CHECK()                                  \
   do {                                                     \

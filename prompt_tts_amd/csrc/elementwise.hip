@@ -12,34 +12,50 @@ inline unsigned grid_for(int64_t work_items) {
 }
 
 // ---- GEGLU --------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NT) void geglu_fwd_kernel(const T* __restrict__ proj, T* __restrict__ out, int64_t M, int64_t F) {
+// IL = interleaved projection columns (the layout the fused GEMM epilogues use, pt_gemm act 2 / 3): value of act column
+// 32 q + t at column 64 q + t, its gate at 64 q + 32 + t.  This kernel pair is the fallback for row counts the fused
+// epilogues do not take (M not a multiple of 256) and the f32 parity mode; `bias` (original order, may be NULL) is added to
+// the projection in place, because a GEMM over the interleaved weight cannot add it in its own epilogue.
+template <bool IL> __device__ __forceinline__ int64_t geglu_col(int64_t c, int64_t F, bool gate) {
+  if (!IL) return gate ? F + c : c;
+  return 64 * (c >> 5) + (c & 31) + (gate ? 32 : 0);
+}
+template <typename T, bool IL>
+__global__ __launch_bounds__(NT) void geglu_fwd_kernel(T* __restrict__ proj, const float* __restrict__ bias, T* __restrict__ out,
+                                                       int64_t M, int64_t F) {
   constexpr int EPC = Vec16<T>::N;
   const int64_t cpr = F / EPC, total = M * cpr;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t m = i / cpr, c = (i - m * cpr) * EPC;
-    Vec16<T> h = load16(proj + m * 2 * F + c), g = load16(proj + m * 2 * F + F + c), o;
+    T* hp = proj + m * 2 * F + geglu_col<IL>(c, F, false); T* gp = proj + m * 2 * F + geglu_col<IL>(c, F, true);
+    Vec16<T> h = load16(hp), g = load16(gp), o;
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { h.set(e, h.get(e) + bias[c + e]); g.set(e, g.get(e) + bias[F + c + e]); }
+      store16(hp, h); store16(gp, g);
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.set(e, h.get(e) * gelu_erf_f(g.get(e)));
     store16(out + m * F + c, o);
   }
 }
-template <typename T>
+template <typename T, bool IL>
 __global__ __launch_bounds__(NT) void geglu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ proj,
                                                        T* __restrict__ dproj, int64_t M, int64_t F) {
   constexpr int EPC = Vec16<T>::N;
   const int64_t cpr = F / EPC, total = M * cpr;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int64_t m = i / cpr, c = (i - m * cpr) * EPC;
-    Vec16<T> h = load16(proj + m * 2 * F + c), g = load16(proj + m * 2 * F + F + c), d = load16(dout + m * F + c), dh, dg;
+    const int64_t hc = m * 2 * F + geglu_col<IL>(c, F, false), gc = m * 2 * F + geglu_col<IL>(c, F, true);
+    Vec16<T> h = load16(proj + hc), g = load16(proj + gc), d = load16(dout + m * F + c), dh, dg;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       const float gv = g.get(e), dv = d.get(e);
       dh.set(e, dv * gelu_erf_f(gv));
       dg.set(e, dv * h.get(e) * gelu_erf_grad_f(gv));
     }
-    store16(dproj + m * 2 * F + c, dh);
-    store16(dproj + m * 2 * F + F + c, dg);
+    store16(dproj + hc, dh);
+    store16(dproj + gc, dg);
   }
 }
 
@@ -287,21 +303,31 @@ extern "C" int pt_ddpm_step(const float* x, const float* eps, const float* z, fl
   return PT_OK;
 }
 
-extern "C" int pt_geglu_fwd(const void* proj, void* out, int64_t M, int64_t F, int dtype, pt_stream stream) {
-  if (M <= 0 || F <= 0 || F % 8 != 0) return PT_ERR_SHAPE;
+extern "C" int pt_geglu_fwd(void* proj, const float* bias, void* out, int64_t M, int64_t F, int interleaved, int dtype, pt_stream stream) {
+  if (M <= 0 || F <= 0 || F % 8 != 0 || (interleaved && F % 32 != 0)) return PT_ERR_SHAPE;
   if (!pt_aligned16(proj) || !pt_aligned16(out)) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (interleaved) {
+    PT_DISPATCH(dtype,
+                hipLaunchKernelGGL((geglu_fwd_kernel<float, true>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (float*)proj, bias, (float*)out, M, F),
+                hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t, true>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (bf16_t*)proj, bias, (bf16_t*)out, M, F));
+  }
   PT_DISPATCH(dtype,
-              hipLaunchKernelGGL((geglu_fwd_kernel<float>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)proj, (float*)out, M, F),
-              hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)proj, (bf16_t*)out, M, F));
+              hipLaunchKernelGGL((geglu_fwd_kernel<float, false>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (float*)proj, bias, (float*)out, M, F),
+              hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t, false>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (bf16_t*)proj, bias, (bf16_t*)out, M, F));
 }
-extern "C" int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int dtype, pt_stream stream) {
-  if (M <= 0 || F <= 0 || F % 8 != 0) return PT_ERR_SHAPE;
+extern "C" int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int64_t F, int interleaved, int dtype, pt_stream stream) {
+  if (M <= 0 || F <= 0 || F % 8 != 0 || (interleaved && F % 32 != 0)) return PT_ERR_SHAPE;
   if (!pt_aligned16(proj) || !pt_aligned16(dout) || !pt_aligned16(dproj)) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (interleaved) {
+    PT_DISPATCH(dtype,
+                hipLaunchKernelGGL((geglu_bwd_kernel<float, true>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)dout, (const float*)proj, (float*)dproj, M, F),
+                hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t, true>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)dout, (const bf16_t*)proj, (bf16_t*)dproj, M, F));
+  }
   PT_DISPATCH(dtype,
-              hipLaunchKernelGGL((geglu_bwd_kernel<float>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)dout, (const float*)proj, (float*)dproj, M, F),
-              hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)dout, (const bf16_t*)proj, (bf16_t*)dproj, M, F));
+              hipLaunchKernelGGL((geglu_bwd_kernel<float, false>), dim3(grid_for(M * F / 4)), dim3(NT), 0, s, (const float*)dout, (const float*)proj, (float*)dproj, M, F),
+              hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t, false>), dim3(grid_for(M * F / 8)), dim3(NT), 0, s, (const bf16_t*)dout, (const bf16_t*)proj, (bf16_t*)dproj, M, F));
 }
 
 template <int OP> static int flat_launch(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream) {

@@ -1,5 +1,6 @@
 // Encodec decoder kernels that do not fit the 128x128 GEMM: RVQ gather-sum, row-streaming conv for few output
 // channels (the 24 kHz end of the SEANet decoder: 16..64 channels, HBM-bound), and the 2-layer LSTM recurrence.
+#include <stdlib.h>
 #include "mma.h"
 
 namespace {
@@ -256,6 +257,180 @@ __global__ __launch_bounds__(256) void lstm2_step_kernel(const LstmParams p, int
   }
 }
 
+
+// ---- persistent 2-layer LSTM (bf16, H = 512): ONE launch for all T steps ---------------------------------------------------
+// The recurrence is T dependent steps of two tiny GEMMs ([B x 512] x [512 x 2048] and [B x 1024] x [1024 x 2048]): as T + 1
+// launches each step re-reads 6 MiB of weights from L2 and pays a launch boundary (~14 us per step at B = 64).  Here the
+// weights are RESIDENT: the batch is cut into clusters of 16 rows (one MFMA tile) and each cluster runs on 64 workgroups, one per
+// CU, workgroup u owning hidden units 8u .. 8u+7 of BOTH layers (4 gates x 8 units = 32 gate columns: 32 KiB + 64 KiB of
+// weights in LDS for the whole kernel, cell states in registers).  Per tick s the workgroup computes layer 0 at t = s and layer 1
+// at t = s - 1 (both need only h0_{s-1} and h1_{s-2}), publishes its 2 x 16 x 8 new hidden values and waits for its 63 peers:
+//   publish: 32 lanes of wave 0 store 16 B each with sc1 (write-through) into hx[s & 1], s_waitcnt vmcnt(0), lane 0 adds 1 to
+//            the cluster's arrival counter (agent-scope atomic);
+//   consume: lane 0 polls the counter with sc1 loads until 64 (s + 1) arrivals, workgroup barrier, then every wave reads the
+//            hidden vectors with sc1 buffer loads straight into MFMA A fragments (no L1 copy can be stale: every load of
+//            exchanged bytes is sc1 -- the measured "one lane signals for the workgroup's sc1 stores / sc1 poll / barrier /
+//            sc1 loads" hand-off of the microarchitecture guide).
+// Two parity buffers suffice: a workgroup can write hx[(s+1) & 1] only after all 64 have arrived at tick s, i.e. after every
+// peer has finished reading hx[(s-1) & 1].  All 64 x clusters <= 256 workgroups must be co-resident: 1 per CU (112 KiB LDS),
+// at most 4 clusters per launch; every spin is bounded and a timeout raises the error word instead of hanging.
+constexpr int LP_UNITS = 8, LP_SLICES = 64, LP_H = 512, LP_COLS = 32;
+constexpr int LP_W0_BYTES = LP_COLS * LP_H * 2, LP_W1_BYTES = LP_COLS * 2 * LP_H * 2, LP_RED_BYTES = 4 * 4 * 4 * 64 * 4;
+constexpr int LP_LDS = LP_W0_BYTES + LP_W1_BYTES + LP_RED_BYTES + 1024;
+struct LstmPersist {
+  int B, T, b_base, clusters;
+  const bf16_t* x; const bf16_t* xg0; const bf16_t* whh0; const bf16_t* wcat1; const float* bias1;
+  bf16_t* out_elu;
+  bf16_t* hx;            // [2 parity][2 layer][clusters * 16][512]
+  unsigned* counters;    // [clusters] arrivals, then [1] error word; zeroed by the launch function
+};
+
+__global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist p) {
+  __shared__ __attribute__((aligned(16))) char smem[LP_LDS];
+  char* W0s = smem; char* W1s = smem + LP_W0_BYTES;
+  float* red = reinterpret_cast<float*>(smem + LP_W0_BYTES + LP_W1_BYTES);
+  bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + LP_W0_BYTES + LP_W1_BYTES + LP_RED_BYTES);     // [2][16][8]
+  int* abort_flag = reinterpret_cast<int*>(smem + LP_W0_BYTES + LP_W1_BYTES + LP_RED_BYTES + 512);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x / LP_SLICES, u = blockIdx.x % LP_SLICES;
+  const int rows = p.clusters * 16;
+  if (tid == 0) *abort_flag = 0;
+
+  // ---- resident weights: local gate column lc = gate * 8 + unit; 16-byte chunk ch of row lc lives at ch ^ (lc & 15) ----
+  for (int q = tid; q < LP_COLS * 64; q += 256) {
+    const int lc = q >> 6, ch = q & 63;
+    const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
+    *reinterpret_cast<u32x4_t*>(W0s + lc * 1024 + ((ch ^ (lc & 15)) << 4)) = *reinterpret_cast<const u32x4_t*>(p.whh0 + grow * LP_H + ch * 8);
+  }
+  for (int q = tid; q < LP_COLS * 128; q += 256) {
+    const int lc = q >> 7, ch = q & 127;
+    const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
+    *reinterpret_cast<u32x4_t*>(W1s + lc * 2048 + ((ch ^ (lc & 15)) << 4)) = *reinterpret_cast<const u32x4_t*>(p.wcat1 + grow * 2 * LP_H + ch * 8);
+  }
+  // ---- gate-math role of this thread: (layer, batch row, unit) ----
+  const int layer = tid >> 7, b = (tid >> 3) & 15, jj = tid & 7;
+  const int bglob = p.b_base + 16 * c + b;
+  const bool bvalid = bglob < p.B;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (layer == 1) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + LP_UNITS * u + jj];
+  }
+  float cstate = 0.f;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hx, 0, 2 * 2 * rows * LP_H * 2, 0x00020000);
+  unsigned* cnt = p.counters + c;
+  unsigned* err = p.counters + p.clusters;
+  __syncthreads();
+
+  for (int s = 0; s <= p.T; ++s) {
+    const bool l0 = s < p.T, l1 = s >= 1;
+    // layer 0's input gates of this tick (independent of the exchange: issued before the wait)
+    float xg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (layer == 0 && l0 && bvalid) {
+      const bf16_t* xp = p.xg0 + ((int64_t)bglob * p.T + s) * (4 * LP_H) + LP_UNITS * u + jj;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) xg[gi] = to_f32<bf16_t>(xp[gi * LP_H]);
+    }
+    if (s >= 1) {                                           // hidden values of tick s - 1 from all 64 workgroups of the cluster
+      if (tid == 0) {
+        const unsigned target = (unsigned)LP_SLICES * (unsigned)s;
+        int spin = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spin > (1 << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *abort_flag = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (*abort_flag) return;
+    }
+    f32x4_t acc[4];                                         // [layer * 2 + tile]: D[row = batch][col = local gate column]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (s >= 1) {
+      const int par = (s - 1) & 1;
+      Frag<bf16_t> a0[4], a1[4];
+      const int voff0 = (((par * 2 + 0) * rows + 16 * c + li) * LP_H + 128 * wave + 8 * g) * 2;
+      const int voff1 = (((par * 2 + 1) * rows + 16 * c + li) * LP_H + 128 * wave + 8 * g) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                         // wave w: k-steps 4w .. 4w+3 of h0_{s-1} (and of h1_{s-2})
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs, voff0 + 64 * k, 0, 16);
+        a0[k].v = __builtin_bit_cast(bf16x8_t, v);
+      }
+      if (s >= 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs, voff1 + 64 * k, 0, 16);
+          a1[k].v = __builtin_bit_cast(bf16x8_t, v);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ks = 4 * wave + k;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const int lc = 16 * tl + li;
+          Frag<bf16_t> w0, w1a;
+          w0.v = *reinterpret_cast<const bf16x8_t*>(W0s + lc * 1024 + (((4 * ks + g) ^ (lc & 15)) << 4));
+          w1a.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((4 * ks + g) ^ (lc & 15)) << 4));
+          if (l0) mma16(acc[tl], a0[k], w0);
+          mma16(acc[2 + tl], a0[k], w1a);
+          if (s >= 2) {
+            Frag<bf16_t> w1b;
+            w1b.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((64 + 4 * ks + g) ^ (lc & 15)) << 4));
+            mma16(acc[2 + tl], a1[k], w1b);
+          }
+        }
+      }
+    }
+    // partial sums of the four waves (each took a quarter of the reduction) -> LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 4 + i) * 4 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+    const bool active = layer == 0 ? l0 : l1;
+    const int t = s - layer;
+    float hn = 0.f;
+    if (active) {
+      float pre[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int tile = layer * 2 + (gi >> 1), src_lane = ((gi & 1) * 8 + jj) + 16 * (b >> 2), r = b & 3;
+        float v = layer == 0 ? xg[gi] : bias[gi];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((w * 4 + tile) * 4 + r) * 64 + src_lane];
+        pre[gi] = v;
+      }
+      const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanhf(pre[2]), og = sigmoid_f(pre[3]);
+      cstate = fg * cstate + ig * gg;
+      hn = og * tanhf(cstate);
+      if (layer == 1 && bvalid) {
+        const int64_t oi = ((int64_t)bglob * p.T + t) * LP_H + LP_UNITS * u + jj;
+        const float v = hn + to_f32<bf16_t>(p.x[oi]);
+        p.out_elu[oi] = from_f32<bf16_t>(v < 0.f ? (__expf(v) - 1.f) : v);
+      }
+    }
+    hstage[(layer * 16 + b) * 8 + jj] = from_f32<bf16_t>(hn);
+    __syncthreads();
+    if (s < p.T) {                                          // publish h0_s and h1_{s-1} (the last tick has no reader)
+      if (tid < 32) {
+        const int pl = tid >> 4, pb = tid & 15;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(hstage + (pl * 16 + pb) * 8);
+        const int voff = ((((s & 1) * 2 + pl) * rows + 16 * c + pb) * LP_H + LP_UNITS * u) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(v, hrs, voff, 0, 16);
+      }
+      if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pt_rvq_decode(const int64_t* codes, const void* codebooks, void* out, int64_t B, int64_t n_q, int64_t T,
@@ -320,6 +495,27 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   p.x = (const char*)d->x; p.xg0 = (const char*)d->xg0; p.whh0 = (const char*)d->whh0; p.wcat1 = (const char*)d->wcat1;
   p.bias1 = d->bias1; p.h0_seq = (char*)d->h0_seq; p.h1_seq = (char*)d->h1_seq; p.c0 = d->c0; p.c1 = d->c1; p.out_elu = (char*)d->out_elu;
   hipStream_t s = (hipStream_t)stream;
+  // persistent form (bf16, H = 512): the recurrence in one launch per <= 64 batch rows, weights resident in LDS; h0_seq is its
+  // exchange workspace (hidden vectors of the current / previous tick + arrival counters), h1_seq / c0 / c1 stay unused
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("PT_LSTM_PERSIST"); persist = e ? atoi(e) : 1; }
+  const int64_t ws_need = 4ll * 64 * LP_H * 2 * 2 + 256;
+  if (persist && dtype == PT_BF16 && d->H == LP_H && d->B * d->T * d->H * 2 >= ws_need) {
+    for (int64_t b0 = 0; b0 < d->B; b0 += 64) {
+      LstmPersist q;
+      q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
+      const int64_t nb = d->B - b0 < 64 ? d->B - b0 : 64;
+      q.clusters = (int)((nb + 15) / 16);
+      q.x = (const bf16_t*)d->x; q.xg0 = (const bf16_t*)d->xg0; q.whh0 = (const bf16_t*)d->whh0; q.wcat1 = (const bf16_t*)d->wcat1;
+      q.bias1 = d->bias1; q.out_elu = (bf16_t*)d->out_elu;
+      q.counters = reinterpret_cast<unsigned*>(d->h0_seq);
+      q.hx = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(d->h0_seq) + 256);
+      if (hipMemsetAsync(d->h0_seq, 0, 256, s) != hipSuccess) return PT_ERR_LAUNCH;
+      hipLaunchKernelGGL(lstm2_persist_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
+      PT_LAUNCH_CHECK();
+    }
+    return PT_OK;
+  }
   dim3 grid((unsigned)(d->H / 16), 2, (unsigned)((d->B + 15) / 16));
   for (int step = 0; step <= (int)d->T; ++step) {
     if (dtype == PT_F32) hipLaunchKernelGGL((lstm2_step_kernel<float>), grid, dim3(256), 0, s, p, step);

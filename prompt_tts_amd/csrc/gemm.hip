@@ -51,6 +51,7 @@ struct GemmParams {
   int act, act2; char* C2; int64_t ldc2;
   float* arow_sum; int64_t arow_n, arow_stride; int arow_rep;
   int tiles_m, tiles_n;
+  int64_t geglu_rows;          // pt_wgrad_group: > 0 = the GEMM's rows are GEGLU-interleaved weight rows (F = geglu_rows)
 };
 
 __device__ __attribute__((aligned(256))) const uint32_t pt_zero_page[64] = {0};
@@ -98,6 +99,14 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
     ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)co * 3 + (2 - tap)) * op.ld + col;
   }
   return reinterpret_cast<const char*>(ptr);
+}
+
+// GEGLU interleave of a [2F]-row weight (value rows 0..F-1, gate rows F..2F-1): interleaved row 64 q + t is value row
+// 32 q + t for t < 32 and gate row F + 32 q + (t - 32) otherwise, so that one lane's accumulator blocks j and j + 2 of a
+// 64-column wave tile hold the value and the gate of the same activation column (fused GEGLU epilogues).
+__host__ __device__ __forceinline__ int64_t geglu_orig_row(int64_t mi, int64_t F) {
+  const int64_t q = mi >> 6; const int t = (int)(mi & 63);
+  return t < 32 ? 32 * q + t : F + 32 * q + (t - 32);
 }
 
 constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
@@ -171,7 +180,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       if (p.bias) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.bias + nbase + 16 * j + 4 * g);
+          // act 2: output columns are GEGLU-interleaved (64 q + t: t < 32 value row 32 q + t, else gate row F + 32 q + t - 32)
+          const int64_t bcol = p.act == 2 ? (j < 2 ? (nbase >> 1) + 16 * j : (p.N >> 1) + (nbase >> 1) + 16 * (j - 2)) : nbase + 16 * j;
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.bias + bcol + 4 * g);
           v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
         }
       }
@@ -182,6 +193,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
           const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
           v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
         }
+      }
+      if (p.act == 3) {
+        // GEGLU backward fused into the ff2 dgrad: the tile holds d(act)[m][jc]; with value / gate read from the saved
+        // (interleaved) projection, C receives d(proj) in the same interleaved layout: per 32-column block q of act,
+        // 64 output columns [d value (32) | d gate (32)] -- one whole 128-byte row segment per block.
+        const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int64_t q64 = 2 * nbase + 64 * h;                  // first interleaved column of this 32-column block
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const u32x2_t hv = *reinterpret_cast<const u32x2_t*>(pr + q64 + 16 * jj + 4 * g);
+            const u32x2_t gv = *reinterpret_cast<const u32x2_t*>(pr + q64 + 32 + 16 * jj + 4 * g);
+            const float val[4] = {__uint_as_float(hv[0] << 16), __uint_as_float(hv[0] & 0xffff0000u),
+                                  __uint_as_float(hv[1] << 16), __uint_as_float(hv[1] & 0xffff0000u)};
+            const float gat[4] = {__uint_as_float(gv[0] << 16), __uint_as_float(gv[0] & 0xffff0000u),
+                                  __uint_as_float(gv[1] << 16), __uint_as_float(gv[1] & 0xffff0000u)};
+            float dv[4], dg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float ge, dge;
+              gelu_erf_fast(gat[r], ge, dge);
+              const float d = v[2 * h + jj][r];
+              dv[r] = d * ge; dg[r] = d * val[r] * dge;
+            }
+            u32x2_t o;
+            o[0] = (uint32_t)f32_to_bf16_bits(dv[0]) | ((uint32_t)f32_to_bf16_bits(dv[1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(dv[2]) | ((uint32_t)f32_to_bf16_bits(dv[3]) << 16);
+            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * jj + (g >> 1)) ^ (li & 7)) << 4)) = o;
+            o[0] = (uint32_t)f32_to_bf16_bits(dg[0]) | ((uint32_t)f32_to_bf16_bits(dg[1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(dg[2]) | ((uint32_t)f32_to_bf16_bits(dg[3]) << 16);
+            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((4 + 2 * jj + (g >> 1)) ^ (li & 7)) << 4)) = o;
+          }
+          bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C) + (mbase + 16 * i) * p.ldc + q64 + 8 * rd_c;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = 8 * it + rd_row;
+            *reinterpret_cast<u32x4_t*>(Cb + r * p.ldc) = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+          }
+        }
+        continue;
       }
       if (p.residual) {
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr + nbase + 4 * g;
@@ -201,7 +253,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
           v[j][2] += __uint_as_float(t[1] << 16); v[j][3] += __uint_as_float(t[1] & 0xffff0000u);
         }
       }
-      for (int op = 0; op < (p.C2 ? 2 : 1); ++op) {
+      if (p.act == 2) {
+        // GEGLU forward fused into the ff1 GEMM: columns are interleaved so that register block j (value) and j + 2 (gate)
+        // of one lane belong to the same act column: C2[m][nbase / 2 + 16 j + 4 g + r] = value * gelu(gate); the raw
+        // projection tile still goes to C below (the backward needs it)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float ge, dge;
+            gelu_erf_fast(v[jj + 2][r], ge, dge);
+            w[r] = v[jj][r] * ge;
+          }
+          u32x2_t o;
+          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          *reinterpret_cast<u32x2_t*>(scratch + li * 64 + (((2 * jj + (g >> 1)) ^ (li & 3)) << 4) + ((g & 1) << 3)) = o;
+        }
+        {
+          const int r = lane >> 2, c = lane & 3;               // 16 rows x 64 bytes: one pass, 16 bytes per lane
+          bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C2) + (mbase + 16 * i + r) * p.ldc2 + (nbase >> 1) + 8 * c;
+          *reinterpret_cast<u32x4_t*>(Cb) = *reinterpret_cast<const u32x4_t*>(scratch + r * 64 + ((c ^ (r & 3)) << 4));
+        }
+      }
+      for (int op = 0; op < ((p.C2 && p.act != 2) ? 2 : 1); ++op) {
         const int act = op == 0 ? p.act : p.act2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -776,7 +852,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int64_t m = m0 + wr * 128 + 64 * h + 16 * wc + li;
-        if (m < p.arow_n) unsafeAtomicAdd(bdst + m, p.alpha * accb[h][0]);
+        if (m < p.arow_n) unsafeAtomicAdd(bdst + (p.geglu_rows > 0 ? geglu_orig_row(m, p.geglu_rows) : m), p.alpha * accb[h][0]);
       }
     }
     return;
@@ -827,7 +903,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void wgrad8p_group_kernel(const Wgra
   gemm8p_body<true, true, 2, 0, KB>(g.p[pid], bid - base, g.slabs + (size_t)bid * (256 * 256), smem);
 }
 
-struct FoldProb { float* C; int64_t ldc, M, N; int tiles_n, ntile, split_k, wg_base; float alpha; int blk_end; };
+struct FoldProb { float* C; int64_t ldc, M, N, geglu_rows; int tiles_n, ntile, split_k, wg_base; float alpha; int blk_end; };
 struct FoldGroup { FoldProb f[PT_WG_MAX]; int nprob; const float* slabs; };
 
 // C[m][n .. n+3] += alpha * sum over the K-slices of the tile's partials; one thread per 16-byte quad of a tile,
@@ -855,7 +931,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const FoldGroup g) {
   const int64_t m = (int64_t)tm * 256 + (wave >> 2) * 128 + 16 * (reg >> 2) + (lane & 15);
   const int64_t n = (int64_t)tn * 256 + (wave & 3) * 64 + 16 * (reg & 3) + 4 * (lane >> 4);
   if (m >= f.M || n >= f.N) return;
-  float* dst = f.C + m * f.ldc + n;
+  float* dst = f.C + (f.geglu_rows > 0 ? geglu_orig_row(m, f.geglu_rows) : m) * f.ldc + n;
   if (n + 3 < f.N && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
     f32x4_t c = *reinterpret_cast<const f32x4_t*>(dst);
     c[0] += f.alpha * s0[0]; c[1] += f.alpha * s0[1]; c[2] += f.alpha * s0[2]; c[3] += f.alpha * s0[3];
@@ -1023,6 +1099,16 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p) {
   p.arow_sum = d->arow_sum; p.arow_n = d->arow_n; p.arow_stride = d->arow_stride; p.arow_rep = d->arow_rep > 0 ? d->arow_rep : 1;
   if (p.arow_sum && (d->out_kind != PT_OUT_F32_ATOMIC || d->arow_n <= 0 || d->arow_n > d->M || (p.arow_rep > 1 && d->arow_stride < d->arow_n))) return PT_ERR_ARG;
   p.tiles_m = p.tiles_n = 0;   // set per tile configuration at launch
+  p.geglu_rows = d->geglu_rows;
+  if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
+  if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
+  if (d->act >= 2) {
+    // fused GEGLU epilogues exist on the predicate-free bf16 path only: whole tiles, 16-byte aligned rows
+    if (dtype != PT_BF16 || d->out_kind != PT_OUT_T || d->M % 256 != 0 || d->N % 256 != 0 || d->ldc % 8 != 0) return PT_ERR_ARG;
+    if (d->act == 2 && (!d->C2 || d->ldc2 % 8 != 0 || d->residual || d->residual2 || d->row_bias)) return PT_ERR_ARG;
+    if (d->act == 3 && (!d->residual || d->ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(d->residual) & 15u) || d->bias ||
+                        d->row_bias || d->residual2 || d->C2 || d->ldc < 2 * d->N)) return PT_ERR_ARG;
+  }
   return PT_OK;
 }
 
@@ -1077,7 +1163,7 @@ extern "C" int pt_wgrad_group(const pt_gemm_desc* descs, int n, float* ws, int64
     g.p[i].split_k = split;
     FoldProb& f = fg.f[i];
     f.C = reinterpret_cast<float*>(g.p[i].C); f.ldc = g.p[i].ldc; f.M = g.p[i].M; f.N = g.p[i].N;
-    f.tiles_n = g.p[i].tiles_n; f.ntile = tiles[i]; f.split_k = split; f.wg_base = base; f.alpha = g.p[i].alpha;
+    f.geglu_rows = g.p[i].geglu_rows; f.tiles_n = g.p[i].tiles_n; f.ntile = tiles[i]; f.split_k = split; f.wg_base = base; f.alpha = g.p[i].alpha;
     base += tiles[i] * split; blk += tiles[i] * 64;
     g.wg_end[i] = base; f.blk_end = blk;
   }

@@ -17,10 +17,20 @@ __device__ __forceinline__ int find_seg(const pt_param_seg* seg, int n_seg, int6
   return lo;
 }
 
+// layout 2 (GEGLU projection weight [2F][cin], F = numel / cin / 2): shadow rows in the interleaved order the fused GEGLU
+// epilogues of pt_gemm expect -- value row 32 q + t at 64 q + t, gate row F + 32 q + t at 64 q + 32 + t.
+__device__ __forceinline__ int64_t geglu_shadow_index(const pt_param_seg& sg, int64_t local) {
+  const int64_t row = local / sg.cin, col = local - row * sg.cin, F = sg.numel / sg.cin / 2;
+  const int64_t r = row < F ? row : row - F;
+  return (64 * (r >> 5) + (r & 31) + (row < F ? 0 : 32)) * sg.cin + col;
+}
+
 template <typename T>
 __device__ __forceinline__ void shadow_store(T* shadow, const pt_param_seg& sg, int64_t local, float val) {
   if (sg.layout == 0) {
     shadow[sg.shadow_offset + local] = from_f32<T>(val);
+  } else if (sg.layout == 2) {
+    shadow[sg.shadow_offset + geglu_shadow_index(sg, local)] = from_f32<T>(val);
   } else {  // Conv1d weight (Cout, Cin, 3) -> [Cout][3][cin_pad]
     const int64_t per_co = (int64_t)sg.cin * 3;
     const int64_t co = local / per_co; const int rem = (int)(local - co * per_co);
@@ -41,11 +51,15 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
     clip = fminf(1.f, max_norm / (nrm + 1e-6f));       // torch.nn.utils.clip_grad_norm_
   }
   __shared__ int s_first;
+  const float decay = 1.f - lr * wd, rbc2 = 1.f / sqrtf(bc2), step = lr / bc1;
   for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < n_total; base += (int64_t)gridDim.x * CHUNK) {
     __syncthreads();
     if (threadIdx.x == 0) s_first = find_seg(seg, n_seg, base);     // one binary search per 4096-element chunk
     __syncthreads();
-    for (int k = threadIdx.x; k < CHUNK; k += NT) {
+    // Quads: every tensor starts on a multiple of 4 elements, so 4 consecutive elements never straddle two tensors.  Plain
+    // (layout 0) quads that lie wholly inside their tensor move as 16-byte loads / stores of p, g, m, v (and an 8-byte shadow
+    // store); conv k=3 tensors (their gradient and shadow are tap-major), tails and padding take the element path.
+    for (int k = threadIdx.x * 4; k < CHUNK; k += NT * 4) {
       const int64_t i = base + k;
       if (i >= n_total) break;
       int si = s_first;
@@ -53,25 +67,44 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
       const pt_param_seg sg = seg[si];
       const int64_t local = i - sg.offset;
       if (local >= sg.numel) continue;                 // alignment padding between tensors
-      float pv = p[i];
-      if (UPDATE && !sg.frozen) {
-        int64_t gi = i;
-        if (sg.layout == 1) {                          // conv k=3 gradients live as [Cout][3][Cin]
-          const int64_t per_co = (int64_t)sg.cin * 3;
-          const int64_t co = local / per_co; const int rem = (int)(local - co * per_co);
-          const int ci = rem / 3, tap = rem - ci * 3;
-          gi = sg.offset + (co * 3 + tap) * sg.cin + ci;
+      if (sg.layout != 1 && local + 3 < sg.numel && i + 3 < n_total && (sg.layout == 0 || (sg.cin & 3) == 0)) {
+        f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + i);
+        if (UPDATE && !sg.frozen) {
+          const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i);
+          f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + i), vv = *reinterpret_cast<const f32x4_t*>(v + i);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * clip;
+            mv[e] = b1 * mv[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pv[e] = pv[e] * decay - step * (mv[e] / (sqrtf(vv[e]) * rbc2 + eps));
+          }
+          *reinterpret_cast<f32x4_t*>(m + i) = mv; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+          *reinterpret_cast<f32x4_t*>(p + i) = pv;
         }
-        const float gv = g[gi] * clip;
-        pv *= 1.f - lr * wd;
-        const float mv = b1 * m[i] + (1.f - b1) * gv;
-        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
-        m[i] = mv; v[i] = vv;
-        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
-        pv -= (lr / bc1) * (mv / denom);
-        p[i] = pv;
+        store4<T>(shadow + sg.shadow_offset + (sg.layout == 2 ? geglu_shadow_index(sg, local) : local), pv[0], pv[1], pv[2], pv[3]);
+        continue;
       }
-      shadow_store<T>(shadow, sg, local, pv);
+      for (int e = 0; e < 4 && local + e < sg.numel && i + e < n_total; ++e) {
+        const int64_t ie = i + e, le = local + e;
+        float pv = p[ie];
+        if (UPDATE && !sg.frozen) {
+          int64_t gi = ie;
+          if (sg.layout == 1) {                        // conv k=3 gradients live as [Cout][3][Cin]
+            const int64_t per_co = (int64_t)sg.cin * 3;
+            const int64_t co = le / per_co; const int rem = (int)(le - co * per_co);
+            const int ci = rem / 3, tap = rem - ci * 3;
+            gi = sg.offset + (co * 3 + tap) * sg.cin + ci;
+          }
+          const float gv = g[gi] * clip;
+          const float mv = b1 * m[ie] + (1.f - b1) * gv;
+          const float vv = b2 * v[ie] + (1.f - b2) * gv * gv;
+          m[ie] = mv; v[ie] = vv;
+          pv = pv * decay - step * (mv / (sqrtf(vv) * rbc2 + eps));
+          p[ie] = pv;
+        }
+        shadow_store<T>(shadow, sg, le, pv);
+      }
     }
   }
 }

@@ -31,12 +31,14 @@ class ParamStore:
     def __init__(self, module, device, dtype):
         self.device, self.dtype, self.pt = device, dtype, ops._DT[dtype]
         self.names, self.params, self.info = [], [], {}
+        self.geglu_ids = set()          # parameters whose shadow rows are GEGLU-interleaved
         off = soff = 0
         segs = []
         # Every ResnetBlock1D.time_emb_proj is packed, in forward order, into ONE contiguous "late" region at the end of
         # the flat buffers (weights, then biases), so the 2L+... per-resnet time-embedding projections of a step are a
         # single GEMM forward and two backward instead of dozens of M = B launches.
         named = list(module.named_parameters())
+        self._model_order = [p for _, p in named]
         is_late = lambda nm: nm.endswith("time_emb_proj.weight") or nm.endswith("time_emb_proj.bias")
         ordered = [(nm, p) for nm, p in named if not is_late(nm)] + \
                   [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.weight")] + \
@@ -47,6 +49,12 @@ class ParamStore:
             late = is_late(name)
             is_conv3 = p.dim() == 3 and p.shape[2] == 3
             frozen = name.endswith("proj_out.weight") or name.endswith("proj_out.bias")
+            # GEGLU projection (diffusers FeedForward.net[0].proj, [2F][d]): in bf16 its shadow rows are interleaved so the ff1
+            # GEMM epilogue can apply value * gelu(gate) in registers (csrc/gemm.hip act 2 / 3)
+            geglu = (GEGLU_FUSED and dtype == torch.bfloat16 and name.endswith("ff.net.0.proj.weight") and p.dim() == 2
+                     and p.shape[0] % 512 == 0 and p.shape[1] % 8 == 0)
+            if geglu:
+                self.geglu_ids.add(id(p))
             if is_conv3:
                 cout, cin = p.shape[0], p.shape[1]
                 cin_pad, cout_pad = _round_up(cin, 8), _round_up(cout, 8)
@@ -56,7 +64,7 @@ class ParamStore:
             else:
                 sn = n
                 cin = cin_pad = 0
-                seg = (off, n, soff, 0, 0, 0, int(frozen))
+                seg = (off, n, soff, 2 if geglu else 0, p.shape[1] if geglu else 0, 0, int(frozen))
                 sshape = (p.shape[0], n // p.shape[0]) if p.dim() >= 2 else (n,)
             self.names.append(name); self.params.append(p)
             self.info[id(p)] = dict(off=off, n=n, soff=soff, sn=sn, sshape=sshape, frozen=frozen, name=name, late=late)
@@ -92,6 +100,11 @@ class ParamStore:
                 p.grad = None
         self.attach_grads()
         self.refresh_shadow()
+
+    def params_in_model_order(self):
+        """Parameters in module.parameters() order (what torch.optim.AdamW(model.parameters()) indexes); self.params is in
+        FLAT-BUFFER order, which moves the time_emb_proj tensors to the end."""
+        return self._model_order
 
     # -- views -------------------------------------------------------------------------------------------
     def w(self, p):
@@ -251,6 +264,36 @@ def join_side_stream(device):
             cur.wait_stream(st)
 
 
+# ---- cross-attention K/V reuse (inference) -----------------------------------------------------------------------------
+# The K/V projections of a cross-attention layer depend only on the text-encoder output and the layer's weights.  Inside
+# `with cross_kv_cache():` (forward-only callers whose conditioning and weights stay fixed: the reverse-diffusion sampler's
+# 1000 denoiser calls, the autoregressive decode loop) each layer projects them once and reuses the buffer afterwards.
+_kv_cache = [None]
+
+
+class cross_kv_cache:
+    def __enter__(self):
+        self.prev = _kv_cache[0]
+        _kv_cache[0] = {}
+        return _kv_cache[0]
+
+    def __exit__(self, *exc):
+        _kv_cache[0] = self.prev
+        return False
+
+
+def cached_cross_kv(layer, ctx_in, compute):
+    """compute() -> (k, v, kvbuf) for `layer` on `ctx_in`; memoised per layer while a cross_kv_cache is active."""
+    cache = _kv_cache[0]
+    if cache is None or torch.is_grad_enabled():
+        return compute()
+    key = id(layer)
+    hit = cache.get(key)
+    if hit is None or hit[0] is not ctx_in:
+        hit = cache[key] = (ctx_in, compute())
+    return hit[1]
+
+
 # ---- grouped weight gradients ------------------------------------------------------------------------------------------
 # bf16 weight gradients are not launched one by one: they are queued (descriptor + references to dy / x) and go out as ONE
 # pt_wgrad_group launch per <= 8 problems (+ one fold launch) on the side stream -- the weight gradients of a transformer
@@ -259,6 +302,7 @@ def join_side_stream(device):
 # 3-10 slices per problem and one set of partials per GROUP (csrc/gemm.hip: wgrad8p_group_kernel).  flush_wgrads() is called
 # before a sub-module is announced to the data-parallel reducer and at the end of backward.
 WGRAD_GROUPED = __import__("os").environ.get("PT_WGRAD_GROUPED", "1") != "0"
+GEGLU_FUSED = WGRAD_GROUPED and __import__("os").environ.get("PT_GEGLU_FUSED", "1") != "0"   # needs the grouped wgrad's fold
 WGRAD_GROUP_WGS = int(__import__("os").environ.get("PT_WGRAD_GROUP_WGS", "256"))
 
 
@@ -272,6 +316,7 @@ class _WgradQueue:
         lst = self.lists[cls]
         if lst and sum(t for _, t, _ in lst) + tiles > WGRAD_GROUP_WGS:
             self.flush(cls)
+            lst = self.lists[cls]          # flush() starts a fresh list
         lst.append((desc, tiles, tensors))
         if len(lst) >= ops.WGRAD_GROUP_MAX:
             self.flush(cls)
@@ -303,7 +348,7 @@ def flush_wgrads(device=None):
             q.flush()
 
 
-def _queue_wgrad(cls, M, N, K, A, B, gw, ldc, gbias, tensors):
+def _queue_wgrad(cls, M, N, K, A, B, gw, ldc, gbias, tensors, geglu_rows=0):
     """Queue dW[M][N] += A^T B for the grouped launch; False if this problem must take the single-launch path."""
     if not WGRAD_GROUPED or _DIAG_SKIP_WGRAD or tensors[0].dtype != torch.bfloat16 or M < 128 or N < 128:
         return False
@@ -314,7 +359,7 @@ def _queue_wgrad(cls, M, N, K, A, B, gw, ldc, gbias, tensors):
     if gbias is not None:
         (gb,), n_rep, rstride = _rep(gbias)
         kw = dict(arow_sum=gb, arow_n=gbias.numel(), arow_rep=n_rep, arow_stride=rstride)
-    desc = ops.gemm_desc(M, N, K, A, B, gw, ldc=ldc, out_kind=L.PT_OUT_F32_ATOMIC, **kw)
+    desc = ops.gemm_desc(M, N, K, A, B, gw, ldc=ldc, out_kind=L.PT_OUT_F32_ATOMIC, geglu_rows=geglu_rows, **kw)
     _wgrad_queue(tensors[0].device).add(cls, desc, tiles, tuple(tensors))   # gw / gb live in the persistent flat buffers
     return True
 
@@ -346,8 +391,9 @@ def linear_fwd(x, w, bias=None, residual=None, residual2=None, out=None, out_f32
     return out
 
 
-def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=None, dx_residual=None):
-    """dy [M,N]; x [M,K]; w [N,K].  Returns dx (optionally dx = dy W + dx_residual, or accumulated in place)."""
+def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=None, dx_residual=None, geglu_rows=0):
+    """dy [M,N]; x [M,K]; w [N,K].  Returns dx (optionally dx = dy W + dx_residual, or accumulated in place).
+    geglu_rows = F: dy's columns and w's rows are in the GEGLU-interleaved order; gw / gbias stay in the original order."""
     M, N = dy.shape
     K = x.shape[1]
     pt = ops.pt_dtype(x)
@@ -358,7 +404,10 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
             kw = dict(arow_sum=gb, arow_n=N, arow_rep=n_rep, arow_stride=rstride)
         ops.gemm(N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, pt, ldc=gw.stride(0),
                  out_kind=L.PT_OUT_F32_ATOMIC, split_k=_split_k(N, K, M, x.dtype), **kw)
-    if not _queue_wgrad(0, N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, gw.stride(0), gbias, (dy, x)):
+    if not _queue_wgrad(0, N, K, M, ops.plain(dy, trans=True), ops.plain(x, trans=True), gw, gw.stride(0), gbias, (dy, x),
+                        geglu_rows=geglu_rows):
+        if geglu_rows:
+            raise RuntimeError("interleaved GEGLU weight gradients need the grouped wgrad path")
         on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None

@@ -84,7 +84,7 @@ def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bi
 
 
 def gemm_desc(M, N, K, A, B, out, ldc=None, out_kind=L.PT_OUT_T, split_k=1, alpha=1.0, arow_sum=None, arow_n=0, arow_rep=1,
-              arow_stride=0):
+              arow_stride=0, geglu_rows=0):
     """A bare pt_gemm_desc (weight-gradient form) for wgrad_group()."""
     d = L.pt_gemm_desc()
     d.M, d.N, d.K = M, N, K
@@ -92,6 +92,7 @@ def gemm_desc(M, N, K, A, B, out, ldc=None, out_kind=L.PT_OUT_T, split_k=1, alph
     d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
     d.out_kind = out_kind; d.split_k = split_k; d.alpha = alpha
     d.arow_sum = _p(arow_sum); d.arow_n = arow_n; d.arow_rep = arow_rep; d.arow_stride = arow_stride
+    d.geglu_rows = geglu_rows
     return d
 
 
@@ -181,14 +182,15 @@ def groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, d
           "pt_groupnorm_bwd")
 
 
-def geglu_fwd(proj, out):
+def geglu_fwd(proj, out, bias=None, interleaved=False):
+    """out = value * gelu(gate); `bias` (f32, original column order) is added to proj in place first."""
     M, F2 = proj.shape
-    check(lib.pt_geglu_fwd(_p(proj), _p(out), M, F2 // 2, pt_dtype(proj), _stream()), "pt_geglu_fwd")
+    check(lib.pt_geglu_fwd(_p(proj), _p(bias), _p(out), M, F2 // 2, int(interleaved), pt_dtype(proj), _stream()), "pt_geglu_fwd")
 
 
-def geglu_bwd(dout, proj, dproj):
+def geglu_bwd(dout, proj, dproj, interleaved=False):
     M, F2 = proj.shape
-    check(lib.pt_geglu_bwd(_p(dout), _p(proj), _p(dproj), M, F2 // 2, pt_dtype(proj), _stream()), "pt_geglu_bwd")
+    check(lib.pt_geglu_bwd(_p(dout), _p(proj), _p(dproj), M, F2 // 2, int(interleaved), pt_dtype(proj), _stream()), "pt_geglu_bwd")
 
 
 def silu_fwd(x, y):
@@ -275,6 +277,12 @@ def ddpm_step(x, eps, z, out, c_eps, c_inv, clip, c_x0, c_xt, sigma):
           "pt_ddpm_step")
 
 
+def rvq_decode(codes, codebooks, out, B, n_q, T, bins, dim):
+    """out[(b,t)][:] = sum_q codebooks[q][codes[b][q][t]][:]  (codes int64 (B, n_q, T); codebooks [n_q][bins][dim])."""
+    _dev(codes, codebooks, out)
+    check(lib.pt_rvq_decode(_p(codes), _p(codebooks), _p(out), B, n_q, T, bins, dim, pt_dtype(out), _stream()), "pt_rvq_decode")
+
+
 def codes_from_continuous(x, bins=1024):
     """(B, n_q, T) f32 in [-1, 1] -> int64 code indices (inverse of the collate normalisation)."""
     x = x.contiguous().float()
@@ -297,16 +305,24 @@ def sample_topk(logits, k=1, uniforms=None, temperature=1.0):
 def profile_one_step(step_fn, capture=None):
     """Run step_fn() once with every pt_* call bracketed by HIP events on the launch stream.
     Returns {label: {calls, ms_total, ms_avg, tflops (GEMM/attention), gflop_avg}} sorted by time.
-    capture: a list that receives (label, descriptor copy, dtype, flops) of every pt_gemm call (replayed by replay_gemms)."""
+    capture: a list that receives (label, entry point, argument copies, flops) of every pt_gemm / pt_wgrad_group call
+    (replayed by replay_captured)."""
     recs = []
     originals = {}
+
+    def gemm_flops(d):
+        return 2.0 * d.M * d.N * d.K
 
     def label_and_flops(name, args):
         if name == "pt_gemm":
             d = args[0]._obj; dt = "bf16" if args[1] == L.PT_BF16 else "f32"
             kind = ("N", "T")[d.A.trans] + ("N", "T")[d.B.trans]
             conv = "conv" if L.PT_V_CONV in (d.A.kind, d.B.kind) else "plain"
-            return f"gemm<{dt},{kind},{'atomic' if d.out_kind == L.PT_OUT_F32_ATOMIC else 'store'}>/{conv}", 2.0 * d.M * d.N * d.K
+            return f"gemm<{dt},{kind},{'atomic' if d.out_kind == L.PT_OUT_F32_ATOMIC else 'store'}>/{conv}", gemm_flops(d)
+        if name == "pt_wgrad_group":
+            arr, n = args[0], args[1]
+            conv = "conv" if any(arr[i].B.kind == L.PT_V_CONV for i in range(n)) else "plain"
+            return f"wgrad_group<bf16>/{conv}", sum(gemm_flops(arr[i]) for i in range(n))
         if name in ("pt_attn_fwd", "pt_attn_bwd"):
             d = args[0]._obj
             return name, (4.0 if name == "pt_attn_fwd" else 14.0) * d.B * d.H * d.Nq * d.Nk * d.D
@@ -317,7 +333,10 @@ def profile_one_step(step_fn, capture=None):
             lab, fl = label_and_flops(name, args)
             if capture is not None and name == "pt_gemm":
                 d = args[0]._obj
-                capture.append((lab, type(d).from_buffer_copy(d), args[1], fl))
+                capture.append((lab, name, (C.byref(type(d).from_buffer_copy(d)),) + tuple(args[1:2]), fl))
+            elif capture is not None and name == "pt_wgrad_group":
+                arr = args[0]
+                capture.append((lab, name, (type(arr).from_buffer_copy(arr),) + tuple(args[1:5]), fl))
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*args)
@@ -348,23 +367,23 @@ def profile_one_step(step_fn, capture=None):
     return out
 
 
-def replay_gemms(captured, label, rounds=3):
-    """Re-issue the captured pt_gemm launches with `label` back to back on the current stream (alone on the chip) and
-    return (calls, average microseconds, TFLOP/s).  The operand buffers of the captured step may have been recycled by the
-    caching allocator: they are still mapped, their contents are irrelevant to the timing, and the outputs (gradient buffers,
-    scratch) are overwritten by the next real step anyway."""
-    sel = [(d, dt, fl) for lab, d, dt, fl in captured if lab == label]
+def replay_captured(captured, label, rounds=3):
+    """Re-issue the captured launches with `label` back to back on the current stream (alone on the chip) and return
+    (calls, average microseconds, TFLOP/s).  The operand buffers of the captured step may have been recycled by the caching
+    allocator: they are still mapped, their contents are irrelevant to the timing, and the outputs (gradient buffers, scratch)
+    are overwritten by the next real step anyway.  Timing only -- never used where values are checked."""
+    sel = [(getattr(lib, fn), args, fl) for lab, fn, args, fl in captured if lab == label]
     if not sel:
         return 0, 0.0, 0.0
     st = _stream()
-    for d, dt, _ in sel:
-        check(lib.pt_gemm(C.byref(d), dt, st), "pt_gemm")
+    for fn, args, _ in sel:
+        check(fn(*args, st), "replay")
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(rounds):
-        for d, dt, _ in sel:
-            lib.pt_gemm(C.byref(d), dt, st)
+        for fn, args, _ in sel:
+            fn(*args, st)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (rounds * len(sel))
     return len(sel), us, sum(f for _, _, f in sel) / len(sel) / us / 1e6

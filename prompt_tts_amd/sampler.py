@@ -8,6 +8,7 @@ decode.  The per-step update is one elementwise kernel (pt_ddpm_step); the denoi
 """
 import torch
 
+from . import engine as E
 from . import ops
 
 
@@ -45,16 +46,27 @@ def sample(model, text_seq_ids, attention_mask, T, n_steps=1000, generator=None,
     x = x_init.to(dev, torch.float32).clone() if x_init is not None else torch.randn(B, n_q, T, device=dev, generator=generator)
     _, ac = schedule()
     ts, ratio = timesteps(n_steps)
-    ids = text_seq_ids.to(dev); mask = attention_mask.to(dev) if attention_mask is not None else None
-    for i, t in enumerate(ts):
-        eps = model(x, torch.full((B,), t, dtype=torch.int64, device=dev), ids, mask).sample
-        c_eps, c_inv, c_x0, c_xt, sigma = step_coefficients(t, t - ratio, ac)
-        z = None
-        if t > 0:
-            z = noises[i].to(dev, torch.float32) if noises is not None else torch.randn(x.shape, device=dev, generator=generator)
-        out = torch.empty_like(x)
-        ops.ddpm_step(x, eps.contiguous(), z, out, c_eps, c_inv, clip, c_x0, c_xt, sigma)
-        x = out
+    ids = text_seq_ids.to(device=dev, dtype=torch.int32).contiguous()
+    mask = attention_mask.to(dev) if attention_mask is not None else None
+    S, cpad = ids.shape[1], model.unet.cpad
+    # the conditioning does not change over the reverse steps: the text encoder runs ONCE and every cross-attention layer
+    # projects its K / V once (E.cross_kv_cache), instead of 1000 times each
+    st.ensure_shadow_fresh()
+    text_emb, _ = model.text_encoder.fwd(st, ids, mask, B, S)
+    with E.cross_kv_cache():
+        for i, t in enumerate(ts):
+            xt = torch.empty(B * T, cpad, dtype=st.dtype, device=dev)
+            ops.bct_to_tokens(x, xt, B, n_q, T, cpad)
+            pred, _ = model.unet.fwd(st, xt, torch.full((B,), t, dtype=torch.int64, device=dev), text_emb, B, T, S)
+            eps = torch.empty(B, n_q, T, dtype=torch.float32, device=dev)
+            ops.tokens_to_bct(pred, eps, B, n_q, T, cpad)
+            c_eps, c_inv, c_x0, c_xt, sigma = step_coefficients(t, t - ratio, ac)
+            z = None
+            if t > 0:
+                z = noises[i].to(dev, torch.float32) if noises is not None else torch.randn(x.shape, device=dev, generator=generator)
+            out = torch.empty_like(x)
+            ops.ddpm_step(x, eps, z, out, c_eps, c_inv, clip, c_x0, c_xt, sigma)
+            x = out
     return x
 
 

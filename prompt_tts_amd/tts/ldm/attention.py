@@ -39,13 +39,14 @@ class Attention(nn.Module):
             kvbuf = None
         else:
             q = E.linear_fwd(x, st.w(self.to_q.weight))
-            fw = st.fused([self.to_k.weight, self.to_v.weight])
-            if fw is not None:
-                kvbuf = E.linear_fwd(ctx_in, fw[0])
-                k, v = kvbuf[:, :C], kvbuf[:, C:]
-            else:
-                k = E.linear_fwd(ctx_in, st.w(self.to_k.weight)); v = E.linear_fwd(ctx_in, st.w(self.to_v.weight))
-                kvbuf = None
+
+            def project_kv():
+                fw = st.fused([self.to_k.weight, self.to_v.weight])
+                if fw is not None:
+                    buf = E.linear_fwd(ctx_in, fw[0])
+                    return buf[:, :C], buf[:, C:], buf
+                return E.linear_fwd(ctx_in, st.w(self.to_k.weight)), E.linear_fwd(ctx_in, st.w(self.to_v.weight)), None
+            k, v, kvbuf = E.cached_cross_kv(self, ctx_in, project_kv)
             qkv = None
         o = torch.empty(B * Nq, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(B, self.heads, Nq, dtype=torch.float32, device=x.device)
@@ -101,21 +102,45 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim)])
 
+    def _fused(self, st, M):
+        """GEGLU in the GEMM epilogues (bf16, whole 256-row tiles): the projection weight's shadow rows are interleaved."""
+        return id(self.net[0].proj.weight) in st.geglu_ids and M % 256 == 0
+
     def fwd(self, st, x, h, residual2=None):
         p1, p2 = self.net[0].proj, self.net[2]
-        proj = E.linear_fwd(x, st.w(p1.weight), st.f(p1.bias))
-        act = torch.empty(x.shape[0], proj.shape[1] // 2, dtype=x.dtype, device=x.device)
-        ops.geglu_fwd(proj, act)
+        M, F2 = x.shape[0], p1.weight.shape[0]
+        act = torch.empty(M, F2 // 2, dtype=x.dtype, device=x.device)
+        if self._fused(st, M):
+            # one launch: proj (interleaved columns, kept for the backward) and act = value * gelu(gate) from the same tile
+            proj = torch.empty(M, F2, dtype=x.dtype, device=x.device)
+            ops.gemm(M, F2, x.shape[1], ops.plain(x), ops.plain(st.w(p1.weight)), proj, ops.pt_dtype(x), bias=st.f(p1.bias),
+                     act=2, out2=act, ldc2=F2 // 2)
+        elif id(p1.weight) in st.geglu_ids:
+            # interleaved weight, but a row count the fused epilogue does not take: stand-alone GEGLU over interleaved columns
+            proj = E.linear_fwd(x, st.w(p1.weight))
+            ops.geglu_fwd(proj, act, bias=st.f(p1.bias), interleaved=True)
+        else:
+            proj = E.linear_fwd(x, st.w(p1.weight), st.f(p1.bias))
+            ops.geglu_fwd(proj, act)
         out = E.linear_fwd(act, st.w(p2.weight), st.f(p2.bias), residual=h, residual2=residual2)
         return out, (x, proj, act)
 
     def bwd(self, st, saved, dout):
         x, proj, act = saved
         p1, p2 = self.net[0].proj, self.net[2]
+        M, F2 = proj.shape
+        if self._fused(st, M):
+            # ff2: weight gradient as usual; its dgrad GEMM turns d(act) into d(proj) in the epilogue (d(act) never reaches HBM)
+            E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias), need_dx=False)
+            dproj = torch.empty_like(proj)
+            ops.gemm(M, F2 // 2, dout.shape[1], ops.plain(dout), ops.plain(st.w(p2.weight), trans=True), dproj, ops.pt_dtype(x),
+                     ldc=F2, act=3, residual=proj, ldr=F2)
+            return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2)
+        il = id(p1.weight) in st.geglu_ids
         dact = E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias))
         dproj = torch.empty_like(proj)
-        ops.geglu_bwd(dact, proj, dproj)
-        return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias))
+        ops.geglu_bwd(dact, proj, dproj, interleaved=il)
+        return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2 if il else 0)
 
 
 class BasicTransformerBlock(nn.Module):

@@ -1,0 +1,95 @@
+"""GPU: the north_star ops with no reference counterpart (SURVEY 8a'): RVQ-codebook logits head, the autoregressive decode
+loop with its K/V cache, causal self-attention + cross-attention blocks.  Build-defined; the oracle is plain PyTorch
+(oracle/ar.py, torch.argmax / torch.topk through oracle/collate.sample_topk) -- parity unpinned by the reference by
+construction.  Tolerances: f32 mode 1e-3 on logits (north_star), bf16 4e-2; indices bit-exact except where the oracle's own
+top-2 logits are closer than the logit tolerance (a tie the two summation orders may break differently)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
+def test_logits_head_at_configs3_size(dev, dtype, tol):
+    """BASELINE configs[3]: 64 prompts x 1024 frames of d_model 512 -> 8 codebooks x 1024 logits each (65 536 x 512 -> 8192)."""
+    from prompt_tts_amd import engine as E
+    from prompt_tts_amd.ar import LogitsHead
+    g = torch.Generator(device=dev).manual_seed(3)
+    head = LogitsHead(512, 8, 1024).to(dev)
+    st = E.ParamStore(head, dev, dtype)
+    rows = 65536 if dtype == torch.bfloat16 else 8192
+    h = (torch.randn(rows, 512, generator=g, device=dev) * 0.5).to(dtype)
+    logits = head.fwd(st, h)
+    assert logits.shape == (rows, 8192) and logits.dtype == dtype
+    w = head.proj.weight.detach().to(dtype).float(); b = head.proj.bias.detach().float()
+    ref = h.float() @ w.t() + b
+    assert relerr(logits, ref) < tol
+    # greedy tokens from those logits: bit-exact against torch.argmax of the SAME logits
+    from prompt_tts_amd import ops
+    idx = ops.sample_topk(logits.view(rows * 8, 1024), 1)
+    assert torch.equal(idx, logits.view(rows * 8, 1024).float().argmax(-1))
+
+
+def _pair(dev, dtype, seed=0, d=256, L=2, n_q=4, bins=128, heads=4, T=96):
+    from oracle import ar as oar
+    from oracle.init import deterministic_init_
+    from prompt_tts_amd.ar import ARCodecDecoder
+    ref = deterministic_init_(oar.ARCodecDecoder(d, L, n_q, bins, heads, max_frames=T), seed + 1)
+    with torch.no_grad():
+        ref.code_embedding.mul_(20.0); ref.bos.mul_(5.0)                     # O(1) inputs
+    m = ARCodecDecoder(d, L, n_q, bins, heads, max_frames=T, dtype=dtype)
+    assert list(m.state_dict()) == list(ref.state_dict())
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(dev)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+def test_teacher_forced_logits_vs_oracle_and_causality(dev, dtype, tol):
+    ref, m = _pair(dev, dtype)
+    g = torch.Generator().manual_seed(1)
+    B, T, S = 3, 96, 40
+    codes = torch.randint(0, 128, (B, 4, T), generator=g); ctx = torch.randn(B, S, 256, generator=g)
+    with torch.no_grad():
+        want = ref(codes, ctx)
+    got = m(codes.to(dev), ctx.to(dev))
+    assert got.shape == (B, T, 4, 128) and relerr(got, want) < tol
+    # causal: frames >= 50 changed -> logits of positions <= 50 unchanged (position t sees frames < t)
+    codes2 = codes.clone(); codes2[:, :, 50:] = torch.randint(0, 128, (B, 4, T - 50), generator=g)
+    got2 = m(codes2.to(dev), ctx.to(dev))
+    assert relerr(got2[:, :51], got[:, :51]) < (1e-5 if dtype == torch.float32 else 1e-2) and relerr(got2[:, 60:], got[:, 60:]) > 1e-3
+
+
+@pytest.mark.parametrize("k", [1, 8])
+def test_generate_with_kv_cache_equals_teacher_forced_decisions(dev, k):
+    """The AR loop (one frame per step, K/V cache, cross K/V projected once) must make, at every step, the decision the
+    oracle makes from the teacher-forced logits of the sequence generated so far -- the cache is exact, not an approximation."""
+    from oracle import collate as oc
+    ref, m = _pair(dev, torch.float32, seed=3)
+    g = torch.Generator().manual_seed(2)
+    B, T, S = 4, 64, 24
+    ctx = torch.randn(B, S, 256, generator=g)
+    u = torch.rand(T, B * 4, generator=g)
+    codes = m.generate(ctx.to(dev), T, k=k, uniforms=u.to(dev) if k > 1 else None, temperature=0.9).cpu()
+    assert codes.shape == (B, 4, T) and int(codes.min()) >= 0 and int(codes.max()) < 128 and len(torch.unique(codes)) > 20
+    with torch.no_grad():
+        logits = ref(codes, ctx)                                                   # oracle logits of the generated sequence
+    bad = 0
+    for t in range(T):
+        lt = logits[:, t].reshape(B * 4, 128)
+        want = oc.sample_topk(lt, k, u[t] if k > 1 else None, temperature=0.9) if k > 1 else lt.argmax(-1)
+        miss = want != codes[:, :, t].reshape(-1)
+        if miss.any():                                                             # only ties within the logit tolerance may differ
+            top2 = lt.topk(min(k + 1, 128), dim=-1).values
+            near = (top2[:, :-1] - top2[:, 1:]).abs().min(-1).values < 1e-3 * float(lt.abs().max())
+            bad += int((miss & ~near).sum())
+            if k > 1:                                                              # or a uniform within tolerance of a CDF edge
+                bad -= int((miss & ~near).sum()); bad += int(miss.sum() > 2)
+    assert bad == 0
+    # the device's own teacher-forced pass agrees with its incremental pass
+    lg = m(codes.to(dev), ctx.to(dev)).cpu()
+    assert relerr(lg, logits) < 1e-3

@@ -74,6 +74,47 @@ def test_hip_decoder_vs_oracle(dev, dtype, tol, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(5, 300), (20, 150), (70, 40)])
+def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, monkeypatch):
+    """bf16 decode at sizes that take the PERSISTENT LSTM (one launch for all T steps, weights resident in LDS, hidden state
+    exchanged between the cluster's 64 workgroups every step): 1, 2 and 4 + 1 clusters (70 rows = two launches), ragged last
+    cluster.  Checked against the CPU oracle (tolerance of test_hip_decoder_vs_oracle) and, tightly, against the same decoder
+    in f32 parity mode, which runs the step-per-launch LSTM."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    W = oe.random_weights(5)
+    codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(B + T))
+    got = EncodecDecoder(W, device=dev, dtype=torch.bfloat16).decode(codes.to(dev)).cpu()
+    f32 = EncodecDecoder(W, device=dev, dtype=torch.float32).decode(codes.to(dev)).cpu()
+    assert torch.isfinite(got).all() and got.shape == (B, 1, 320 * T)
+    assert float((got - f32).abs().max() / f32.abs().max()) < 6e-2
+    rel_rms = float((got - f32).pow(2).mean().sqrt() / f32.pow(2).mean().sqrt())
+    assert rel_rms < 1.5e-2, rel_rms                                   # a wrong hand-off corrupts whole rows, not the last bits
+    want = oe.decode(codes[:2], W)
+    assert float((got[:2] - want).abs().max() / want.abs().max()) < 6e-2
+
+
+@pytest.mark.gpu
+def test_decode_at_configs3_size_bf16_vs_f32_and_oracle(dev):
+    """BASELINE configs[3]: 64 prompts x 1024 frames.  bf16 (the bench dtype, persistent LSTM over 1024 recurrent steps) against
+    the f32 parity-mode decoder on all 64 items, and one item against the CPU oracle (f32, T = 1024).  Stated bound for the
+    1024-step bf16 recurrence: 8e-2 of the waveform peak, 2e-2 relative RMS."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    W = oe.random_weights(6)
+    codes = torch.randint(0, 1024, (64, 8, 1024), generator=torch.Generator().manual_seed(64))
+    bf = EncodecDecoder(W, device=dev, dtype=torch.bfloat16).decode(codes.to(dev)).cpu()
+    f32 = EncodecDecoder(W, device=dev, dtype=torch.float32).decode(codes.to(dev)).cpu()
+    assert bf.shape == (64, 1, 327680) and torch.isfinite(bf).all()
+    peak = float(f32.abs().max())
+    assert float((bf - f32).abs().max()) < 8e-2 * peak
+    assert float((bf - f32).pow(2).mean().sqrt() / f32.pow(2).mean().sqrt()) < 2e-2
+    want = oe.decode(codes[17:18], W)                                   # CPU oracle, one full-length item
+    assert float((f32[17:18] - want).abs().max()) < 1e-3 * float(want.abs().max())
+    assert float((bf[17:18] - want).abs().max()) < 8e-2 * float(want.abs().max())
+
+
+@pytest.mark.gpu
 def test_hip_decoder_batch_items_independent(dev):
     """Full-size property (size independent): decoding a batch equals decoding its items one by one; causal in time."""
     from oracle import encodec as oe
@@ -171,11 +212,40 @@ def test_encode_codec_tar_plumbing_cpu(tmp_path):
         assert tf.extractfile("utt1.len.txt").read() == b"25.0" and tf.extractfile("utt0.txt").read() == b"hello 0"
         code = np.load(io.BytesIO(tf.extractfile("utt1.npy").read()))
         assert code.dtype == np.int64 and code.shape == (8, 75) and code[0, 0] == 600
-    with pytest.raises(ValueError):                     # no resampler in this build: other rates are refused, not mangled
+    # other sample rates are resampled to 24 kHz (generate_code.py:28 convert_audio): length ceil(n * 24000 / rate); a tone stays
+    # the same tone (band-limited sinc interpolation, torchaudio Resample defaults), 24-bit PCM is read too
+    import math
+    for rate, width in ((16000, 2), (44100, 3), (24000, 2)):
+        n = 3000
+        tone = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / rate)
         buf = io.BytesIO()
         with wave.open(buf, "wb") as w:
-            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(b"\0\0" * 10)
-        buf.seek(0); ec.read_wav(buf)
+            w.setnchannels(1); w.setsampwidth(width); w.setframerate(rate)
+            if width == 2:
+                w.writeframes((tone * 32767).astype("<i2").tobytes())
+            else:
+                v = (tone * 8388607).astype(np.int32)
+                w.writeframes(np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], 1).astype(np.uint8).tobytes())
+        buf.seek(0)
+        got = ec.read_wav(buf)
+        m = int(math.ceil(n * 24000 / rate))
+        assert got.shape == (1, m) and got.dtype == torch.float32
+        want = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(m) / 24000.0)
+        inner = slice(64, m - 64)                                        # away from the zero-padded edges of the finite signal
+        assert float(np.abs(got[0].numpy()[inner] - want[inner]).max()) < 2e-3
+    assert torch.equal(ec.resample(torch.ones(2, 10), 8000, 8000), torch.ones(2, 10))
+    # no weights loaded: generate() / decode() refuse instead of silently using a random codec
+    ec._model = None
+    with pytest.raises(RuntimeError):
+        ec.generate([torch.zeros(1, 1, 320)])
+    with pytest.raises(RuntimeError):
+        ec.load_encoder(None)
+    import decode_codec as dc
+    dc._model = None
+    with pytest.raises(RuntimeError):
+        dc.decode(torch.zeros(1, 8, 10, dtype=torch.long))
+    with pytest.raises(BaseException):
+        dc.decode(torch.zeros(8, 10, dtype=torch.long))                 # the reference's shape check comes first
 
 
 @pytest.mark.gpu

@@ -238,3 +238,59 @@ def test_wgrad_group_resnet_convs(dev):
                                      checks[1][0], out_kind=L.PT_OUT_F32_ATOMIC)]
     with pytest.raises(RuntimeError):
         ops.wgrad_group(mixed, _ws(dev))
+
+
+# ---- GEGLU fused into the ff1 GEMM epilogue (act 2) and into the ff2 dgrad epilogue (act 3) ----------------------------------
+def _interleave_rows(w, F):
+    """[2F][...] value rows | gate rows -> the interleaved order of pt_gemm act 2 (row 64q+t: t<32 value 32q+t, else gate)."""
+    idx = torch.arange(2 * F, device=w.device)
+    q, t = idx // 64, idx % 64
+    src = torch.where(t < 32, 32 * q + t, F + 32 * q + (t - 32))
+    return w[src].contiguous(), src
+
+
+@pytest.mark.parametrize("M,d,F", [(32768, 512, 2048), (512, 256, 1024), (8192, 512, 256)])
+def test_geglu_fused_forward_backward(dev, M, d, F):
+    """FeedForward of the reference's BasicTransformerBlock (diffusers GEGLU: Linear(d, 2F) -> value * gelu_erf(gate)) through
+    the fused epilogues, against plain PyTorch f32 on the same bf16-rounded inputs; the 512-row case runs on the 128 x 128
+    kernel, the others on the eight-phase kernel."""
+    import torch.nn.functional as Fn
+    from prompt_tts_amd import engine as E
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = _gen(dev, 9)
+    x, xf = rnd((M, d), dtype, dev, g); w1, w1f = rnd((2 * F, d), dtype, dev, g, d ** -0.5)
+    b1 = torch.randn(2 * F, generator=g, device=dev) * 0.1
+    w1i, src = _interleave_rows(w1, F)
+    proj = torch.full((M, 2 * F), float("nan"), dtype=dtype, device=dev); act = torch.full((M, F), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(M, 2 * F, d, ops.plain(x), ops.plain(w1i), proj, ops._DT[dtype], bias=b1, act=2, out2=act, ldc2=F)
+    pref = xf @ w1f.t() + b1
+    assert relerr(proj, pref[:, src]) < TOL[dtype]                       # raw projection, interleaved columns, bias in place
+    aref = pref[:, :F] * Fn.gelu(pref[:, F:])
+    assert relerr(act, aref) < TOL[dtype]
+    # backward of the following Linear(F, d): d(act) = dout W2 never leaves the kernel; d(proj) comes out interleaved
+    dout, doutf = rnd((M, d), dtype, dev, g); w2, w2f = rnd((d, F), dtype, dev, g, F ** -0.5)
+    dproj = torch.full((M, 2 * F), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(M, F, d, ops.plain(dout), ops.plain(w2, trans=True), dproj, ops._DT[dtype], ldc=2 * F, act=3, residual=proj, ldr=2 * F)
+    pr = proj.float()[:, torch.argsort(src)].clone().requires_grad_(True)          # the stored (bf16-rounded) projection, un-interleaved
+    (pr[:, :F] * Fn.gelu(pr[:, F:])).backward(doutf @ w2f)
+    assert relerr(dproj, pr.grad[:, src]) < TOL[dtype]
+    # the stand-alone interleaved kernels (row counts the fused epilogue does not take) agree with the fused ones
+    proj2 = torch.empty_like(proj); act2 = torch.empty_like(act)
+    ops.gemm(M, 2 * F, d, ops.plain(x), ops.plain(w1i), proj2, ops._DT[dtype])
+    ops.geglu_fwd(proj2, act2, bias=b1, interleaved=True)
+    assert relerr(proj2, proj.float()) < 1e-2 and relerr(act2, act.float()) < 1e-2
+    dact = torch.empty(M, F, dtype=dtype, device=dev)
+    ops.gemm(M, F, d, ops.plain(dout), ops.plain(w2, trans=True), dact, ops._DT[dtype])
+    dproj2 = torch.empty_like(dproj); ops.geglu_bwd(dact, proj, dproj2, interleaved=True)
+    assert relerr(dproj2, dproj.float()) < 2e-2
+    # weight / bias gradient of the interleaved projection through the grouped wgrad: written in the ORIGINAL row order
+    gw = torch.zeros(2 * F, d, dtype=torch.float32, device=dev); gb = torch.zeros(2 * F, dtype=torch.float32, device=dev)
+    ws = torch.empty(ops.wgrad_group_ws_floats(256), dtype=torch.float32, device=dev)
+    ops.wgrad_group([ops.gemm_desc(2 * F, d, M, ops.plain(dproj, trans=True), ops.plain(x, trans=True), gw, out_kind=L.PT_OUT_F32_ATOMIC,
+                                   arow_sum=gb, arow_n=2 * F, geglu_rows=F)], ws)
+    dpo = dproj.float()[:, torch.argsort(src)]
+    assert relerr(gw, dpo.t() @ xf) < TOL[dtype] and relerr(gb, dpo.sum(0)) < TOL[dtype]
+    # misuse is refused before any launch
+    with pytest.raises(RuntimeError):
+        ops.gemm(M + 8, 2 * F, d, ops.plain(x), ops.plain(w1i), proj, ops._DT[dtype], bias=b1, act=2, out2=act, ldc2=F)

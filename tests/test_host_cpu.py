@@ -171,8 +171,9 @@ def test_cabi_refuses_bad_arguments_with_a_status_never_a_launch():
     assert lib.pt_rowconv(ctypes.byref(r), L.PT_BF16, None) == -1                   # more than 64 output channels
     l = L.pt_lstm2_desc(); l.B, l.T, l.H = 4, 10, 300
     assert lib.pt_lstm2_forward(ctypes.byref(l), L.PT_BF16, None) == -1             # hidden size must be a multiple of 256
-    assert lib.pt_geglu_fwd(OKP, OKP, 16, 12, L.PT_BF16, None) == -1
-    assert lib.pt_geglu_fwd(OKP, OKP, 16, 16, 9, None) == -2                        # unknown dtype
+    assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 12, 0, L.PT_BF16, None) == -1
+    assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 16, 0, 9, None) == -2                # unknown dtype
+    assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 16, 1, L.PT_BF16, None) == -1       # interleaved needs F % 32 == 0
 
 
 def test_product_never_imports_oracle_or_reference():
@@ -252,3 +253,39 @@ def test_create_dataloader_shards_indices_not_collated_batches():
     assert len(batches) == len(dl) == 2 and all(b["code"].shape[0] == 4 for b in batches)
     # 10 items, batches of 4, 2 ranks: [0..3] [4..7] [8,9,0,1] [2,3,4,5]; rank 1 reads ONLY its own two batches
     assert calls == [4, 5, 6, 7, 2, 3, 4, 5]
+
+
+def test_async_checkpoint_writer_and_adamw_state_dict_format(tmp_path):
+    """optim_N.pt has torch.optim.AdamW.state_dict() structure (train.py:142) and round-trips through the flat store;
+    the writer snapshots first and serialises in the background."""
+    from types import SimpleNamespace
+    from prompt_tts_amd import checkpoint
+    lin = torch.nn.Linear(4, 3); frozen = torch.nn.Parameter(torch.zeros(5))
+    params = [lin.weight, frozen, lin.bias]
+    info, off = {}, 0
+    for p, fz, name in zip(params, (False, True, False), ("w", "proj_out.bias", "b")):
+        info[id(p)] = {"off": off, "n": p.numel(), "frozen": fz, "name": name}; off += 64
+    store = SimpleNamespace(info=info, adam_m=torch.arange(off, dtype=torch.float32), adam_v=torch.arange(off, dtype=torch.float32) * 2,
+                            step_count=7, device=torch.device("cpu"), flat_p=torch.zeros(off), names=["w", "proj_out.bias", "b"],
+                            params_in_model_order=lambda: params)
+    hyper = dict(lr=1e-5, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    sd = checkpoint.adamw_state_dict(store, 5e-6, hyper)
+    assert sorted(sd["state"]) == [0, 2] and sd["param_groups"][0]["params"] == [0, 1, 2]          # the unused parameter: no state
+    assert sd["state"][0]["exp_avg"].shape == (3, 4) and float(sd["state"][2]["step"]) == 7.0
+    ref = torch.optim.AdamW(params, **hyper)
+    ref.load_state_dict(sd)                                                                        # torch accepts the structure
+    assert set(ref.state_dict()["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+    w = checkpoint.AsyncCheckpointWriter()
+    path = str(tmp_path / "optim_1.pt")
+    w.save(path, sd)
+    store.adam_m.zero_()                                                                           # after save(): not in the file
+    w.wait()
+    back = torch.load(path)
+    assert torch.equal(back["state"][0]["exp_avg"], torch.arange(12, dtype=torch.float32).view(3, 4)) and not os.path.exists(path + ".tmp")
+    store.adam_v.zero_(); store.step_count = 0
+    checkpoint.load_adamw_state_dict(store, back)
+    assert store.step_count == 7 and torch.equal(store.adam_m[:12], torch.arange(12, dtype=torch.float32))
+    assert torch.equal(store.adam_v[128:131], torch.arange(128, 131, dtype=torch.float32) * 2) and float(store.adam_m[64:69].abs().sum()) == 0
+    w.save(str(tmp_path / "no_such_dir" / "x.pt"), {"a": 1})
+    with pytest.raises(Exception):
+        w.wait()

@@ -376,6 +376,17 @@ def test_elementwise(dev, dtype):
     out = torch.empty(M, Fh, dtype=dtype, device=dev); dproj = torch.empty_like(proj)
     ops.geglu_fwd(proj, out); ops.geglu_bwd(dout, proj, dproj)
     assert relerr(out, ref) < TOL[dtype] and relerr(dproj, pr.grad) < TOL[dtype]
+    # interleaved column order (pt_gemm act 2 / 3 layout) + in-place bias: same function of permuted inputs
+    idx = torch.arange(2 * Fh); q, t = idx // 64, idx % 64
+    src = torch.where(t < 32, 32 * q + t, Fh + 32 * q + (t - 32))
+    bias = torch.randn(2 * Fh, generator=g)
+    pil = proj[:, src.to(dev)].contiguous(); out2 = torch.empty_like(out); dpil = torch.empty_like(pil)
+    ops.geglu_fwd(pil, out2, bias=bias.to(dev), interleaved=True)
+    pb = (pf + bias).clone().requires_grad_(True)
+    hb, gb_ = pb.chunk(2, -1); refb = hb * F.gelu(gb_); refb.backward(df)
+    assert relerr(out2, refb) < TOL[dtype] and relerr(pil, (pf + bias)[:, src]) < TOL[dtype]
+    ops.geglu_bwd(dout, pil, dpil, interleaved=True)
+    assert relerr(dpil, pb.grad[:, src]) < TOL[dtype] * 2
     x, xf = rnd((1000 + 3,), dtype, dev, g); dy, dyf = rnd((1003,), dtype, dev, g)
     xr = xf.clone().requires_grad_(True); F.silu(xr).backward(dyf)
     y = torch.empty_like(x); dx = torch.empty_like(x)

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from prompt_tts_amd import parallel
+from prompt_tts_amd import checkpoint, parallel
 from prompt_tts_amd.tts.dataloader import DeviceFeeder, SyntheticDataset, create_dataloader
 from prompt_tts_amd.tts.models import TTSSingleSpeaker
 
@@ -77,15 +77,15 @@ def main(args):
         # the resume the reference never wrote (it only saves, train.py:139-144): model, Adam moments + step, LR-schedule
         # position and the noise / timestep generator of this rank, from the files written at the end of that epoch
         model.load_state_dict(torch.load(args.ckpt_dir + f"ckpt_{args.resume_epoch}.pt", map_location=dev))
-        opt = torch.load(args.ckpt_dir + f"optim_{args.resume_epoch}.pt", map_location=dev)
-        if opt["names"] != st.names:
-            raise RuntimeError("optimizer checkpoint does not match this model's parameter list")
-        st.adam_m = opt["exp_avg"].to(dev).clone(); st.adam_v = opt["exp_avg_sq"].to(dev).clone(); st.step_count = int(opt["step"])
-        opt_step, global_step = int(opt.get("opt_step", st.step_count)), int(opt.get("global_step", st.step_count * accum))
-        if "gen_state" in opt and rank < len(opt["gen_state"]):
-            gen.set_state(opt["gen_state"][rank].cpu())
+        checkpoint.load_adamw_state_dict(st, torch.load(args.ckpt_dir + f"optim_{args.resume_epoch}.pt", map_location="cpu"))
+        extra_path = args.ckpt_dir + f"resume_{args.resume_epoch}.pt"
+        extra = torch.load(extra_path, map_location="cpu") if os.path.exists(extra_path) else {}
+        opt_step, global_step = int(extra.get("opt_step", st.step_count)), int(extra.get("global_step", st.step_count * accum))
+        if "gen_state" in extra and rank < len(extra["gen_state"]):
+            gen.set_state(extra["gen_state"][rank].cpu())
         start_epoch = args.resume_epoch
         logging.info(f"resumed after epoch {start_epoch}: optimizer step {opt_step}")
+    writer_ckpt = checkpoint.AsyncCheckpointWriter(dev) if rank == 0 else None
     for epoch in range(start_epoch, config["num_train_epochs"]):
         logging.info(f"Starting epoch {epoch}:")
         torch.manual_seed(epoch)                                            # same shuffle on every rank (accelerate C7)
@@ -131,11 +131,16 @@ def main(args):
             gen_states = gathered
             torch.distributed.barrier()
         if rank == 0 and epoch % config["save_per_epochs"] == 0:
-            # same file names as the reference, which concatenates ckpt_dir and the name without a separator
-            torch.save(model.state_dict(), args.ckpt_dir + f"ckpt_{epoch + 1}.pt")
-            torch.save({"step": st.step_count, "exp_avg": st.adam_m, "exp_avg_sq": st.adam_v, "names": st.names,
-                        "opt_step": opt_step, "global_step": global_step, "gen_state": gen_states},
-                       args.ckpt_dir + f"optim_{epoch + 1}.pt")
+            # same file names as the reference, which concatenates ckpt_dir and the name without a separator; optim_N.pt is a
+            # torch.optim.AdamW state_dict (train.py:142).  Snapshots go to pinned host memory on a copy stream and are
+            # written by a background thread: the next epoch starts at once.
+            writer_ckpt.wait()
+            writer_ckpt.save(args.ckpt_dir + f"ckpt_{epoch + 1}.pt", model.state_dict())
+            writer_ckpt.save(args.ckpt_dir + f"optim_{epoch + 1}.pt", checkpoint.adamw_state_dict(st, ADAMW["lr"] * lam(opt_step), ADAMW))
+            writer_ckpt.save(args.ckpt_dir + f"resume_{epoch + 1}.pt",
+                             {"opt_step": opt_step, "global_step": global_step, "gen_state": gen_states})
+    if writer_ckpt is not None:
+        writer_ckpt.wait()
     if writer is not None:
         writer.flush(); writer.close()
     if world > 1:
