@@ -210,6 +210,10 @@ int pt_geglu_bwd(const void* dout, const void* proj, void* dproj, int64_t M, int
 int pt_silu_fwd(const void* x, void* y, int64_t n, int dtype, pt_stream stream);
 int pt_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, pt_stream stream);
 
+/* torch.nn.Dropout (diffusers Attention.to_out[1], FeedForward.net[1]; tts/models.py:95-100 forwards text_encoder_dropout):
+ * y = x * keep[i] * scale [+ residual], keep = 1 byte per element (drawn by the caller), scale = 1 / (1 - p); the backward is the
+ * same call on dy.  n a multiple of 16 bytes of elements; y may alias x. */
+int pt_dropout(const void* x, const uint8_t* keep, const void* residual, void* y, int64_t n, float scale, int dtype, pt_stream stream);
 /* y = a + b (flat), y may alias a. */
 int pt_add(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream);
 /* y[r] = x[2r] + x[2r+1] over rows of C (dgrad of nearest x2 upsample). rows = output rows. */

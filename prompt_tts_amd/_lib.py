@@ -88,6 +88,7 @@ SIGNATURES = {
     "pt_silu_fwd": [_vp, _vp, _i64, _i32, _vp],
     "pt_silu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "pt_add": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "pt_dropout": [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp],
     "pt_pairsum_rows": [_vp, _vp, _i64, _i64, _i32, _vp],
     "pt_colsum": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _vp],
     "pt_embedding_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],

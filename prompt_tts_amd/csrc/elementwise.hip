@@ -74,6 +74,26 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(const float* __restrict__
   }
 }
 
+// ---- dropout (torch.nn.Dropout in the text encoder's BasicTransformerBlocks, tts/models.py:95-100): y = x * mask * scale
+// [+ residual]; the keep mask (1 byte per element) is drawn by the host side (device RNG or injected), so forward and
+// backward -- the same kernel on dy -- see the same mask.  n multiple of the 16-byte vector.
+template <typename T>
+__global__ __launch_bounds__(NT) void dropout_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, const T* __restrict__ res,
+                                                     T* __restrict__ y, int64_t n, float scale) {
+  constexpr int EPC = Vec16<T>::N;
+  const int64_t nv = n / EPC;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += (int64_t)gridDim.x * NT) {
+    Vec16<T> v = load16(x + i * EPC), r, o;
+    if (res) r = load16(res + i * EPC);
+    uint8_t m[EPC];
+    if (EPC == 8) *reinterpret_cast<uint64_t*>(m) = *reinterpret_cast<const uint64_t*>(mask + i * EPC);
+    else *reinterpret_cast<uint32_t*>(m) = *reinterpret_cast<const uint32_t*>(mask + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.set(e, (m[e] ? v.get(e) * scale : 0.f) + (res ? r.get(e) : 0.f));
+    store16(y + i * EPC, o);
+  }
+}
+
 // ---- flat unary/binary ------------------------------------------------------------------------------------
 template <typename T, int OP>   // 0 silu fwd (a=x) ; 1 silu bwd (a=dy, b=x) ; 2 add
 __global__ __launch_bounds__(NT) void flat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
@@ -346,6 +366,18 @@ extern "C" int pt_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, i
 extern "C" int pt_add(const void* a, const void* b, void* y, int64_t n, int dtype, pt_stream stream) {
   if (!b) return PT_ERR_ARG;
   return flat_launch<2>(a, b, y, n, dtype, stream);
+}
+
+extern "C" int pt_dropout(const void* x, const uint8_t* mask, const void* residual, void* y, int64_t n, float scale, int dtype,
+                          pt_stream stream) {
+  const int epc = dtype == PT_F32 ? 4 : 8;
+  if (n <= 0 || n % epc != 0) return PT_ERR_SHAPE;
+  if (!x || !mask || !y) return PT_ERR_ARG;
+  if (!pt_aligned16(x) || !pt_aligned16(y) || (residual && !pt_aligned16(residual)) || (reinterpret_cast<uintptr_t>(mask) & 7u)) return PT_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  PT_DISPATCH(dtype,
+              hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n / 4)), dim3(NT), 0, s, (const float*)x, mask, (const float*)residual, (float*)y, n, scale),
+              hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid_for(n / 8)), dim3(NT), 0, s, (const bf16_t*)x, mask, (const bf16_t*)residual, (bf16_t*)y, n, scale));
 }
 
 extern "C" int pt_pairsum_rows(const void* x, void* y, int64_t rows, int64_t C, int dtype, pt_stream stream) {

@@ -264,6 +264,18 @@ def join_side_stream(device):
             cur.wait_stream(st)
 
 
+# ---- dropout keep masks ---------------------------------------------------------------------------------------------------
+# The keep mask of a dropout site is drawn on the device with torch's generator (device RNG streams are never compared with
+# the reference's); tests inject masks through `dropout_mask_hook(shape, p) -> uint8 tensor`.
+dropout_mask_hook = [None]
+
+
+def dropout_keep_mask(shape, p, device):
+    if dropout_mask_hook[0] is not None:
+        return dropout_mask_hook[0](tuple(shape), p).to(device=device, dtype=torch.uint8).contiguous()
+    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+
+
 # ---- cross-attention K/V reuse (inference) -----------------------------------------------------------------------------
 # The K/V projections of a cross-attention layer depend only on the text-encoder output and the layer's weights.  Inside
 # `with cross_kv_cache():` (forward-only callers whose conditioning and weights stay fixed: the reverse-diffusion sampler's

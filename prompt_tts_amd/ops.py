@@ -201,6 +201,12 @@ def silu_bwd(dy, x, dx):
     check(lib.pt_silu_bwd(_p(dy), _p(x), _p(dx), x.numel(), pt_dtype(x), _stream()), "pt_silu_bwd")
 
 
+def dropout(x, keep, y, scale, residual=None):
+    """y = x * keep * scale [+ residual]; keep: uint8 tensor of x's shape (1 = kept)."""
+    _dev(x, keep, y)
+    check(lib.pt_dropout(_p(x), _p(keep), _p(residual), _p(y), x.numel(), scale, pt_dtype(x), _stream()), "pt_dropout")
+
+
 def add(a, b, y):
     check(lib.pt_add(_p(a), _p(b), _p(y), a.numel(), pt_dtype(a), _stream()), "pt_add")
 

@@ -18,6 +18,7 @@ class Attention(nn.Module):
         kv = query_dim if cross_attention_dim is None else cross_attention_dim
         self.heads, self.dim_head, self.is_cross = heads, dim_head, cross_attention_dim is not None
         self.scale = dim_head ** -0.5
+        self.p_drop = float(dropout)
         self.to_q = nn.Linear(query_dim, inner, bias=False)
         self.to_k = nn.Linear(kv, inner, bias=False)
         self.to_v = nn.Linear(kv, inner, bias=False)
@@ -51,14 +52,26 @@ class Attention(nn.Module):
         o = torch.empty(B * Nq, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(B, self.heads, Nq, dtype=torch.float32, device=x.device)
         ops.attn_fwd(q, k, v, o, lse, B, self.heads, Nq, Nk, self.dim_head, self.scale, causal, kv_len)
-        out = E.linear_fwd(o, st.w(self.to_out[0].weight), st.f(self.to_out[0].bias), residual=h)
-        return out, (x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, qkv is not None, kvbuf is not None)
+        keep = None
+        if self.p_drop > 0.0 and self.training:
+            # to_out = [Linear, Dropout]: out = h + dropout(o W^T + b): the residual moves from the GEMM epilogue to the dropout
+            y = E.linear_fwd(o, st.w(self.to_out[0].weight), st.f(self.to_out[0].bias))
+            keep = E.dropout_keep_mask(y.shape, self.p_drop, y.device)
+            out = torch.empty_like(y)
+            ops.dropout(y, keep, out, 1.0 / (1.0 - self.p_drop), residual=h)
+        else:
+            out = E.linear_fwd(o, st.w(self.to_out[0].weight), st.f(self.to_out[0].bias), residual=h)
+        return out, (x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, qkv is not None, kvbuf is not None, keep)
 
     # dout: grad of (h + attn(x)); returns (dx wrt normalised input, dctx or None); dctx_accum accumulates in place
     def bwd(self, st, saved, dout, dctx_accum=None):
-        x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, fused_qkv, fused_kv = saved
+        x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, fused_qkv, fused_kv, keep = saved
         C = self.heads * self.dim_head
         wo = self.to_out[0]
+        if keep is not None:                          # through the dropout: d(o W^T + b) = dout * keep / (1 - p)
+            dy = torch.empty_like(dout)
+            ops.dropout(dout, keep, dy, 1.0 / (1.0 - self.p_drop))
+            dout = dy
         do = E.linear_bwd(dout, o, st.w(wo.weight), st.g(wo.weight), st.g(wo.bias))
         delta = torch.empty_like(lse)
         if fused_qkv:
@@ -101,10 +114,12 @@ class FeedForward(nn.Module):
     def __init__(self, dim, mult=4, dropout=0.0):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim)])
+        self.p_drop = float(dropout)
 
     def _fused(self, st, M):
-        """GEGLU in the GEMM epilogues (bf16, whole 256-row tiles): the projection weight's shadow rows are interleaved."""
-        return id(self.net[0].proj.weight) in st.geglu_ids and M % 256 == 0
+        """GEGLU in the GEMM epilogues (bf16, whole 256-row tiles): the projection weight's shadow rows are interleaved.
+        With an active dropout between GEGLU and the second Linear the stand-alone kernels run instead."""
+        return id(self.net[0].proj.weight) in st.geglu_ids and M % 256 == 0 and not (self.p_drop > 0.0 and self.training)
 
     def fwd(self, st, x, h, residual2=None):
         p1, p2 = self.net[0].proj, self.net[2]
@@ -122,14 +137,18 @@ class FeedForward(nn.Module):
         else:
             proj = E.linear_fwd(x, st.w(p1.weight), st.f(p1.bias))
             ops.geglu_fwd(proj, act)
+        keep = None
+        if self.p_drop > 0.0 and self.training:       # net = [GEGLU, Dropout, Linear]
+            keep = E.dropout_keep_mask(act.shape, self.p_drop, act.device)
+            ops.dropout(act, keep, act, 1.0 / (1.0 - self.p_drop))
         out = E.linear_fwd(act, st.w(p2.weight), st.f(p2.bias), residual=h, residual2=residual2)
-        return out, (x, proj, act)
+        return out, (x, proj, act, keep)
 
     def bwd(self, st, saved, dout):
-        x, proj, act = saved
+        x, proj, act, keep = saved
         p1, p2 = self.net[0].proj, self.net[2]
         M, F2 = proj.shape
-        if self._fused(st, M):
+        if keep is None and self._fused(st, M):
             # ff2: weight gradient as usual; its dgrad GEMM turns d(act) into d(proj) in the epilogue (d(act) never reaches HBM)
             E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias), need_dx=False)
             dproj = torch.empty_like(proj)
@@ -138,18 +157,22 @@ class FeedForward(nn.Module):
             return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2)
         il = id(p1.weight) in st.geglu_ids
         dact = E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias))
+        if keep is not None:
+            ops.dropout(dact, keep, dact, 1.0 / (1.0 - self.p_drop))
         dproj = torch.empty_like(proj)
         ops.geglu_bwd(dact, proj, dproj, interleaved=il)
         return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2 if il else 0)
 
 
 class BasicTransformerBlock(nn.Module):
-    """h += attn1(LN1 h); [h += attn2(LN2 h, ctx)]; h += ff(LN3 h).  Dropout p=0 in every BASELINE config."""
+    """h += attn1(LN1 h); [h += attn2(LN2 h, ctx)]; h += ff(LN3 h).  dropout > 0 (the reference forwards
+    text_encoder_dropout, tts/models.py:95-100) acts in training mode after each attention's output projection and between
+    GEGLU and the second feed-forward Linear, as in diffusers' Attention.to_out[1] / FeedForward.net[1]."""
 
     def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, cross_attention_dim=None):
         super().__init__()
-        if dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (every BASELINE config uses 0)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
         self.attn1 = Attention(dim, None, num_attention_heads, attention_head_dim, dropout)
         self.ff = FeedForward(dim, dropout=dropout)
         if cross_attention_dim is not None:

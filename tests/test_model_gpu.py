@@ -229,3 +229,68 @@ def test_weight_shadow_follows_load_state_dict_and_torch_optimizer(dev, dtype, t
     l1, _ = a.train_step(xt, noise, t, ids, mask)
     l2, _ = fresh.train_step(xt, noise, t, ids, mask)
     assert abs(float(l1) - float(l2)) < tol * abs(float(l2))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_text_encoder_dropout_with_injected_masks(dev, dtype, tol):
+    """text_encoder_dropout > 0 (forwarded by the reference at tts/models.py:95-100 into diffusers' Attention.to_out[1] and
+    FeedForward.net[1]): training-mode forward + backward with the SAME keep masks injected on both sides (device RNG streams
+    are never compared), eval mode = no dropout."""
+    from oracle import model as om
+    from oracle.init import deterministic_init_
+    from prompt_tts_amd import engine as E
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    z, cfg = load("small256")
+    cfg = dict(cfg, text_encoder_dropout=0.25, text_encoder_layers=2)
+    xt = torch.from_numpy(z["xt"]); t = torch.from_numpy(z["t"]); ids = torch.from_numpy(z["ids"]); mask = torch.from_numpy(z["mask"])
+    noise = torch.from_numpy(z["noise"])
+    masks = {}
+
+    def keep(shape, p):
+        n = len(masks)                                             # call order: block 0 attention, block 0 FF, block 1 ...
+        g = torch.Generator().manual_seed(1000 + n)
+        rows = shape[0] if len(shape) == 2 else shape[0] * shape[1]
+        m = (torch.rand(rows, shape[-1], generator=g) >= p).to(torch.uint8)
+        masks[n] = m
+        return m
+
+    class InjectedDropout(torch.nn.Module):
+        def __init__(self, p):
+            super().__init__(); self.p = p
+        def forward(self, x):
+            if not self.training:
+                return x
+            m = keep(tuple(x.shape), self.p).view(x.shape).to(x.dtype)
+            return x * m / (1.0 - self.p)
+    ref = deterministic_init_(om.TTSSingleSpeaker(cfg), 9)
+    for blk in ref.text_encoder.transformer_blocks:
+        blk.attn1.to_out[1] = InjectedDropout(0.25); blk.ff.net[1] = InjectedDropout(0.25)
+    ref.train()
+    want = ref(xt, t, ids, mask).sample
+    F.mse_loss(want, noise).backward()
+    n_ref = len(masks)
+    assert n_ref == 4
+    masks.clear()
+    m = deterministic_init_(TTSSingleSpeaker(cfg, dtype=dtype), 9).to(dev)
+    m.train()
+    E.dropout_mask_hook[0] = keep
+    try:
+        got = m(xt.to(dev), t.to(dev), ids.to(dev), mask.to(dev)).sample
+        assert len(masks) == n_ref
+        F.mse_loss(got, noise.to(dev)).backward()
+    finally:
+        E.dropout_mask_hook[0] = None
+    assert relerr(got, want) < tol
+    named = dict(m.named_parameters()); rn = dict(ref.named_parameters())
+    for key in ("text_encoder.transformer_blocks.0.attn1.to_out.0.weight", "text_encoder.transformer_blocks.1.ff.net.0.proj.weight",
+                "text_encoder.transformer_blocks.0.ff.net.2.bias", "text_encoder.word_embedding.weight"):
+        assert relerr(named[key].grad, rn[key].grad) < (tol if dtype == torch.float32 else 1e-1), key
+    # eval mode: dropout inactive, no masks drawn; and the device path draws its own masks when none are injected
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert relerr(m(xt.to(dev), t.to(dev), ids.to(dev), mask.to(dev)).sample, ref(xt, t, ids, mask).sample) < tol
+    m.train()
+    with torch.no_grad():
+        a = m(xt.to(dev), t.to(dev), ids.to(dev), mask.to(dev)).sample
+        b = m(xt.to(dev), t.to(dev), ids.to(dev), mask.to(dev)).sample
+    assert relerr(a, b) > 1e-4                                        # two draws, two different outputs

@@ -94,3 +94,25 @@ def test_device_feeder_delivers_the_same_batches_in_order(dev):
     next(it)
     with pytest.raises(ValueError, match="broken shard"):
         next(it)
+
+
+@pytest.mark.gpu
+def test_two_ranks_odd_batch_count_end_of_epoch(dev, tmp_path):
+    """2 ranks (gloo, sharing the one GPU), 18 items in batches of 4 = 5 batches: an odd count.  Rank r takes batches r, r+2, ...
+    and the tail wraps around (accelerate's shard policy for the reference's loader), so both ranks run 3 steps per epoch and
+    meet in every collective -- no rank is left alone in an all-reduce at the end of an epoch; gradient accumulation of 2
+    leaves one micro-batch over, which is stepped on the last batch instead of being dropped."""
+    d = str(tmp_path) + os.sep
+    cfg = dict(_config(2)); cfg["gradient_accumulation_steps"] = 2
+    json.dump(cfg, open(d + "cfg.json", "w"))
+    env = dict(os.environ, PT_TRAIN_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "train.py"), "--synthetic", "18", "--config_file", d + "cfg.json",
+           "--log_dir", d, "--ckpt_dir", d, "--batch_size", "4", "--max_seq_length", "64", "--dtype", "f32", "--log_every", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, timeout=600, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    extra = torch.load(d + "resume_2.pt", map_location="cpu")
+    # per rank and epoch: 3 micro-batches -> optimizer steps after micro-batch 2 and (end of epoch) after micro-batch 3
+    assert extra["global_step"] == 6 and extra["opt_step"] == 4 and len(extra["gen_state"]) == 2
+    sd = torch.load(d + "ckpt_2.pt", map_location="cpu")
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())

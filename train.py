@@ -47,12 +47,16 @@ def lr_lambda(name, num_warmup_steps, num_training_steps):
 def main(args):
     config = json.load(open(args.config_file, "r"))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("PT_TRAIN_BACKEND", "nccl")             # "gloo": rehearse the N-rank path on one GPU
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            torch.distributed.init_process_group(backend)
     try:
         from torch.utils.tensorboard import SummaryWriter
         writer = SummaryWriter(log_dir=args.log_dir) if rank == 0 else None
