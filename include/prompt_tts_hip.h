@@ -31,7 +31,7 @@ enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -320,6 +320,19 @@ typedef struct pt_lstm2_desc {
   void* h0_seq; void* h1_seq; float* c0; float* c1; void* out_elu;
 } pt_lstm2_desc;
 int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
+
+/* Fused 24 kHz tail of the decoder (bf16): last transposed conv (cin 64 -> r = 2 x cout 32), its residual block (conv k3 32 -> 16,
+ * 1x1 16 -> 32 + 1x1 shortcut, ELUs) and the final conv k7 32 -> 1, in one launch -- the part of EncodecModel.decode
+ * (decode_codec.py:16) that runs at the output sample rate.  x: [B*n][ldx] ELU'd input rows; weights in the matrix forms of the
+ * separate launches: wt [64][128] (row rho*32+co, col tap*64+ci), w3 [16][96], wf [32][64] (cols: 16 of the k3 branch | 32 of x1 |
+ * zero pad), wfin [1][224]; biases f32; wav: [B][2n] f32.  Intermediates are rounded to bf16 where the separate launches round. */
+typedef struct pt_encodec_tail_desc {
+  int64_t B, n; int32_t cin, cout, r, _pad;
+  const void* x; int64_t ldx;
+  const void* wt; const float* bt; const void* w3; const float* b3; const void* wf; const float* bf; const void* wfin; const float* bfin;
+  float* wav;
+} pt_encodec_tail_desc;
+int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.

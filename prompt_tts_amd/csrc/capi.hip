@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 14; }
+extern "C" int pt_abi_version(void) { return 15; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
@@ -24,6 +24,7 @@ extern "C" int pt_struct_size(int which) {
     case 4: return (int)sizeof(pt_rowconv_desc);
     case 5: return (int)sizeof(pt_lstm2_desc);
     case 6: return (int)sizeof(pt_fold_seg);
+    case 7: return (int)sizeof(pt_encodec_tail_desc);
     default: return -1;
   }
 }

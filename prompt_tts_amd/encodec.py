@@ -62,6 +62,9 @@ def _pad_cols(m, mult):
     return out
 
 
+FUSED_TAIL = __import__("os").environ.get("PT_ENCODEC_FUSED_TAIL", "1") != "0"
+
+
 class EncodecDecoder:
     sample_rate = 24000
 
@@ -140,8 +143,21 @@ class EncodecDecoder:
         ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
         check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
         xe, n = ze, T                     # xe = ELU(stage input), n = rows per batch item
-        for st in self.stages:
+        fuse_tail = (self.dtype == torch.bfloat16 and FUSED_TAIL and
+                     (self.stages[-1]["r"], self.stages[-1]["cin"], self.stages[-1]["cout"]) == (2, 64, 32) and n * 160 >= 8)
+        for si, st in enumerate(self.stages):
             r, cin, cout = st["r"], st["cin"], st["cout"]
+            if fuse_tail and si == len(self.stages) - 1:
+                # the 24 kHz end in ONE launch: transposed conv + residual block + final conv, intermediates in LDS
+                wav = torch.empty(B * n * r, 1, dtype=torch.float32, device=self.device)
+                td = L.pt_encodec_tail_desc()
+                td.B, td.n, td.cin, td.cout, td.r = B, n, cin, cout, r
+                td.x, td.ldx = xe.data_ptr(), xe.stride(0)
+                td.wt, td.bt, td.w3, td.b3 = st["wt"].data_ptr(), st["bt"].data_ptr(), st["w3"].data_ptr(), st["b3"].data_ptr()
+                td.wf, td.bf, td.wfin, td.bfin = st["wf"].data_ptr(), st["bf"].data_ptr(), self.wfin.data_ptr(), self.bfin.data_ptr()
+                td.wav = wav.data_ptr()
+                check(lib.pt_encodec_tail(C.byref(td), pt, ops._stream()), "pt_encodec_tail")
+                return wav.view(B, 1, n * r)
             Min, Mout, n_out = B * n, B * n * r, n * r
             x1 = self._empty(Min, r * cout)
             x1e = None

@@ -95,6 +95,27 @@ def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 7), (3, 33), (2, 101)])
+def test_fused_24khz_tail_equals_the_separate_launches(dev, B, T, monkeypatch):
+    """pt_encodec_tail (last transposed conv + residual block + final conv in one launch, intermediates in LDS) against the
+    four row-streaming launches it replaces, same bf16 rounding points: item starts (reflect padding), tile seams (64-row
+    tiles + 5-row halo; 33 and 101 frames are not multiples of anything) and item ends."""
+    import prompt_tts_amd.encodec as pe
+    from oracle import encodec as oe
+    dec = pe.EncodecDecoder(oe.random_weights(8), device=dev, dtype=torch.bfloat16)
+    codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(T)).to(dev)
+    monkeypatch.setattr(pe, "FUSED_TAIL", True)
+    fused = dec.decode(codes).cpu()
+    monkeypatch.setattr(pe, "FUSED_TAIL", False)
+    sep = dec.decode(codes).cpu()
+    assert fused.shape == sep.shape == (B, 1, 320 * T)
+    peak = float(sep.abs().max())
+    assert float((fused - sep).abs().max()) < 4e-3 * peak, float((fused - sep).abs().max()) / peak     # same roundings, other summation order
+    want = oe.decode(codes.cpu(), oe.random_weights(8))
+    assert float((fused - want).abs().max()) < 6e-2 * float(want.abs().max())
+
+
+@pytest.mark.gpu
 def test_decode_at_configs3_size_bf16_vs_f32_and_oracle(dev):
     """BASELINE configs[3]: 64 prompts x 1024 frames.  bf16 (the bench dtype, persistent LSTM over 1024 recurrent steps) against
     the f32 parity-mode decoder on all 64 items, and one item against the CPU oracle (f32, T = 1024).  Stated bound for the
