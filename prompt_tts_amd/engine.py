@@ -39,11 +39,18 @@ class ParamStore:
         # single GEMM forward and two backward instead of dozens of M = B launches.
         named = list(module.named_parameters())
         self._model_order = [p for _, p in named]
-        is_late = lambda nm: nm.endswith("time_emb_proj.weight") or nm.endswith("time_emb_proj.bias")
+        # Likewise the K / V projections of every UNet cross-attention layer (they all read the same text-encoder output) are
+        # packed into one [sum 2C][d_ctx] matrix: one forward GEMM, one dgrad and one weight gradient per step instead of one per
+        # layer (12 launches of M = B*S rows each, far too small to fill the chip).  "Late" tensors are excluded from block spans
+        # (their gradients complete at the END of backward): the data-parallel reducer picks them up in finish().
+        is_tp = lambda nm: nm.endswith("time_emb_proj.weight") or nm.endswith("time_emb_proj.bias")
+        is_kv = lambda nm: KV_BATCHED and nm.startswith("unet.") and (nm.endswith(".attn2.to_k.weight") or nm.endswith(".attn2.to_v.weight"))
+        is_late = lambda nm: is_tp(nm) or is_kv(nm)
         ordered = [(nm, p) for nm, p in named if not is_late(nm)] + \
                   [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.weight")] + \
-                  [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.bias")]
-        self.late = {"w": [], "b": []}
+                  [(nm, p) for nm, p in named if nm.endswith("time_emb_proj.bias")] + \
+                  [(nm, p) for nm, p in named if is_kv(nm)]
+        self.late = {"w": [], "b": [], "kv": []}
         for name, p in ordered:
             n = p.numel()
             late = is_late(name)
@@ -70,9 +77,17 @@ class ParamStore:
             self.info[id(p)] = dict(off=off, n=n, soff=soff, sn=sn, sshape=sshape, frozen=frozen, name=name, late=late)
             segs.append(seg)
             if late:
-                if n % 4 != 0:
-                    raise ValueError("time_emb_proj tensors must be multiples of 4 elements")
-                self.late["w" if name.endswith("weight") else "b"].append(p)
+                if n % 8 != 0:
+                    raise ValueError("packed (late) tensors must be multiples of 8 elements")
+                kind = "kv" if is_kv(name) else ("w" if name.endswith("weight") else "b")
+                if kind == "kv" and not self.late["kv"]:  # the packed K/V matrix is a GEMM operand: start it on a 256-byte line
+                    shift = _round_up(off, ALIGN) - off
+                    shift_s = _round_up(soff, ALIGN) - soff
+                    off += shift; soff += shift_s
+                    seg = (off, n, soff) + seg[3:]
+                    self.info[id(p)].update(off=off, soff=soff)
+                    segs[-1] = seg
+                self.late[kind].append(p)
                 off += n; soff += n                       # packed back to back
             else:
                 off += _round_up(n, ALIGN); soff += _round_up(sn, ALIGN)
@@ -147,6 +162,22 @@ class ParamStore:
         if not infos:
             return 0, 0
         return min(i["off"] for i in infos), max(i["off"] + _round_up(i["n"], ALIGN) for i in infos)
+
+    def late_kv_views(self):
+        """(W [sum 2C][d_ctx] shadow, dW f32, {id(weight): first row}) over the packed cross-attention K/V projections, or None."""
+        ps = self.late["kv"]
+        if not ps:
+            return None
+        i0 = self.info[id(ps[0])]
+        cols = ps[0].shape[1]
+        rows, where = 0, {}
+        for p in ps:
+            if p.shape[1] != cols or self.info[id(p)]["off"] != i0["off"] + rows * cols:
+                return None
+            where[id(p)] = rows
+            rows += p.shape[0]
+        return (self.shadow[i0["soff"]:i0["soff"] + rows * cols].view(rows, cols),
+                self.flat_g[i0["off"]:i0["off"] + rows * cols].view(rows, cols), where)
 
     def late_views(self):
         """(W [Ct][K] f32 master, dW, b [Ct], db) over all time_emb_proj tensors, or None when there are none."""
@@ -306,6 +337,14 @@ def cached_cross_kv(layer, ctx_in, compute):
     return hit[1]
 
 
+# ---- batched cross-attention K/V (training) --------------------------------------------------------------------------------
+# Unet1DConditionModel.fwd / bwd project K and V of ALL cross-attention layers with one GEMM over the packed weights
+# (ParamStore.late_kv_views) and hand each layer its column slices here: {id(attn2 module): (k, v)} in forward,
+# {id(attn2 module): (dk, dv)} -- slices of one d(kv) buffer -- in backward.
+batched_kv = [None]
+batched_dkv = [None]
+
+
 # ---- grouped weight gradients ------------------------------------------------------------------------------------------
 # bf16 weight gradients are not launched one by one: they are queued (descriptor + references to dy / x) and go out as ONE
 # pt_wgrad_group launch per <= 8 problems (+ one fold launch) on the side stream -- the weight gradients of a transformer
@@ -314,6 +353,7 @@ def cached_cross_kv(layer, ctx_in, compute):
 # 3-10 slices per problem and one set of partials per GROUP (csrc/gemm.hip: wgrad8p_group_kernel).  flush_wgrads() is called
 # before a sub-module is announced to the data-parallel reducer and at the end of backward.
 WGRAD_GROUPED = __import__("os").environ.get("PT_WGRAD_GROUPED", "1") != "0"
+KV_BATCHED = __import__("os").environ.get("PT_KV_BATCHED", "1") != "0"
 GEGLU_FUSED = WGRAD_GROUPED and __import__("os").environ.get("PT_GEGLU_FUSED", "1") != "0"   # needs the grouped wgrad's fold
 WGRAD_GROUP_WGS = int(__import__("os").environ.get("PT_WGRAD_GROUP_WGS", "256"))
 

@@ -47,7 +47,12 @@ class Attention(nn.Module):
                     buf = E.linear_fwd(ctx_in, fw[0])
                     return buf[:, :C], buf[:, C:], buf
                 return E.linear_fwd(ctx_in, st.w(self.to_k.weight)), E.linear_fwd(ctx_in, st.w(self.to_v.weight)), None
-            k, v, kvbuf = E.cached_cross_kv(self, ctx_in, project_kv)
+            pre = E.batched_kv[0].get(id(self)) if E.batched_kv[0] is not None else None
+            if pre is not None:                  # projected for every layer at once by the UNet (packed K/V weights)
+                k, v = pre
+                kvbuf = "batched"
+            else:
+                k, v, kvbuf = E.cached_cross_kv(self, ctx_in, project_kv)
             qkv = None
         o = torch.empty(B * Nq, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(B, self.heads, Nq, dtype=torch.float32, device=x.device)
@@ -61,11 +66,13 @@ class Attention(nn.Module):
             ops.dropout(y, keep, out, 1.0 / (1.0 - self.p_drop), residual=h)
         else:
             out = E.linear_fwd(o, st.w(self.to_out[0].weight), st.f(self.to_out[0].bias), residual=h)
-        return out, (x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, qkv is not None, kvbuf is not None, keep)
+        kv_mode = 2 if isinstance(kvbuf, str) else (1 if kvbuf is not None else 0)
+        return out, (x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, qkv is not None, kv_mode, keep)
 
     # dout: grad of (h + attn(x)); returns (dx wrt normalised input, dctx or None); dctx_accum accumulates in place
     def bwd(self, st, saved, dout, dctx_accum=None):
-        x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, fused_qkv, fused_kv, keep = saved
+        x, ctx_in, q, k, v, o, lse, B, Nq, Nk, causal, kv_len, fused_qkv, kv_mode, keep = saved
+        fused_kv = kv_mode == 1
         C = self.heads * self.dim_head
         wo = self.to_out[0]
         if keep is not None:                          # through the dropout: d(o W^T + b) = dout * keep / (1 - p)
@@ -79,7 +86,9 @@ class Attention(nn.Module):
             dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
         else:
             dq = torch.empty(B * Nq, C, dtype=x.dtype, device=x.device)
-            if fused_kv:
+            if kv_mode == 2:                       # slices of the UNet's d(kv) buffer; their dgrad / wgrad run once, batched
+                dk, dv = E.batched_dkv[0][id(self)]
+            elif fused_kv:
                 dkv = torch.empty(B * Nk, 2 * C, dtype=x.dtype, device=x.device)
                 dk, dv = dkv[:, :C], dkv[:, C:]
             else:
@@ -95,6 +104,8 @@ class Attention(nn.Module):
             dx = E.linear_bwd(dv, x, st.w(self.to_v.weight), st.g(self.to_v.weight), dx_accum=dx)
             return dx, None
         dx = E.linear_bwd(dq, x, st.w(self.to_q.weight), st.g(self.to_q.weight))
+        if kv_mode == 2:
+            return dx, dctx_accum
         if fused_kv:
             w, gw = st.fused([self.to_k.weight, self.to_v.weight])
             dctx = E.linear_bwd(dkv, ctx_in, w, gw, dx_accum=dctx_accum)

@@ -95,6 +95,7 @@ class Unet1DConditionModel(nn.Module):
             r._tp_off = off
             off += r.out_channels
         self._tp_total = off
+        self._cross_attn = [m.attn2 for m in self.modules() if m.__class__.__name__ == "BasicTransformerBlock" and m.attn2 is not None]
         self.conv_norm_out = nn.GroupNorm(norm_num_groups, boc[0], eps=norm_eps)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv1d(boc[0], out_channels, 3, padding=1)
@@ -123,6 +124,35 @@ class Unet1DConditionModel(nn.Module):
         tp = lambda r: tproj_all[:, r._tp_off:r._tp_off + r.out_channels]
         tape["time"] = (t_emb, e1, s1, emb, semb)
 
+        # K / V of every cross-attention layer in ONE GEMM over the packed weights (they all read `ctx`); each layer gets its
+        # column slices through E.batched_kv.  Inside a cross_kv_cache (sampler: fixed conditioning) the product is reused.
+        tape["kv"] = None
+        kvp = st.late_kv_views()
+        if kvp is not None:
+            Wkv, _, where = kvp
+            cache = E._kv_cache[0] if not torch.is_grad_enabled() else None
+            hit = cache.get("kv_all") if cache is not None else None
+            if hit is not None and hit[0] is ctx:
+                kv_all = hit[1]
+            else:
+                kv_all = E.linear_fwd(ctx, Wkv)
+                if cache is not None:
+                    cache["kv_all"] = (ctx, kv_all)
+            slices = {}
+            for a in self._cross_attn:
+                rk, rv, C = where[id(a.to_k.weight)], where[id(a.to_v.weight)], a.to_k.weight.shape[0]
+                slices[id(a)] = (kv_all[:, rk:rk + C], kv_all[:, rv:rv + C])
+            E.batched_kv[0] = slices
+            tape["kv"] = (ctx, kv_all.shape[1])
+        try:
+            return self._fwd_blocks(st, xt, tp, tape, ctx, B, T, S, N0=T)
+        finally:
+            E.batched_kv[0] = None
+
+    def _fwd_blocks(self, st, xt, tp, tape, ctx, B, T, S, N0):
+        cfg = self.cfg
+        C0 = cfg["block_out_channels"][0]
+        dev = xt.device
         h, _ = E.conv3_fwd(xt, st.w(self.conv_in.weight), st.f(self.conv_in.bias), B, T, cin=self.cpad, cout=C0)
         tape["conv_in"] = xt
         skips = [(h, T)]
@@ -189,6 +219,29 @@ class Unet1DConditionModel(nn.Module):
         dtp = lambda r: dtp_all[:, r._tp_off:r._tp_off + r.out_channels]
         notify = on_ready or (lambda m: None)
 
+        dkv_all = None
+        if tape.get("kv") is not None:
+            ctx_kv, R = tape["kv"]
+            _, _, where = st.late_kv_views()
+            dkv_all = torch.empty(ctx_kv.shape[0], R, dtype=ctx_kv.dtype, device=ctx_kv.device)    # every slice is fully written
+            E.batched_dkv[0] = {id(a): (dkv_all[:, where[id(a.to_k.weight)]:where[id(a.to_k.weight)] + a.to_k.weight.shape[0]],
+                                        dkv_all[:, where[id(a.to_v.weight)]:where[id(a.to_v.weight)] + a.to_v.weight.shape[0]])
+                                for a in self._cross_attn}
+        try:
+            dctx = self._bwd_blocks(st, tape, dpred, notify, dtp_all, dtp)
+        finally:
+            E.batched_dkv[0] = None
+        if dkv_all is not None:
+            # d(ctx) and the packed K/V weight gradient of all cross-attention layers: one dgrad, one (queued) wgrad
+            Wkv, gWkv, _ = st.late_kv_views()
+            dctx = E.linear_bwd(dkv_all, ctx_kv, Wkv, gWkv, dx_accum=dctx)
+        return dctx
+
+    def _bwd_blocks(self, st, tape, dpred, notify, dtp_all, dtp):
+        cfg = self.cfg
+        B, T, S = tape["dims"]
+        C0 = cfg["block_out_channels"][0]
+        t_emb, e1, s1, emb, semb = tape["time"]
         h, a, s = tape["out"]
         da = E.conv3_bwd(dpred, a, st.w(self.conv_out.weight), st.g(self.conv_out.weight), st.g(self.conv_out.bias),
                          B, T, T, cin=C0, cout=self.cpad)
