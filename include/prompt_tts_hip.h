@@ -31,7 +31,7 @@ enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -333,6 +333,18 @@ typedef struct pt_encodec_tail_desc {
   float* wav;
 } pt_encodec_tail_desc;
 int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stream stream);
+
+/* Fused decoder stage (bf16) for (cin, cout, r) = (128, 64, 4): transposed conv + residual block (conv k3 cout -> cout/2, 1x1 +
+ * 1x1 shortcut, ELUs) in one launch -- the 3 kHz -> 12 kHz stage of EncodecModel.decode.  x: [B*n][ldx] ELU'd input rows;
+ * wt [r*cout][2*cin], w3 [cout/2][3*cout], wf [cout][cout/2 + cout] in the matrix forms of the separate launches; y: [B*r*n][ldy]
+ * ELU'd output rows (the next stage's input). */
+typedef struct pt_encodec_stage_desc {
+  int64_t B, n; int32_t cin, cout, r, _pad;
+  const void* x; int64_t ldx;
+  const void* wt; const float* bt; const void* w3; const float* b3; const void* wf; const float* bf;
+  void* y; int64_t ldy;
+} pt_encodec_stage_desc;
+int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.

@@ -64,6 +64,12 @@ class pt_encodec_tail_desc(C.Structure):
                 ("wf", C.c_void_p), ("bf", C.c_void_p), ("wfin", C.c_void_p), ("bfin", C.c_void_p), ("wav", C.c_void_p)]
 
 
+class pt_encodec_stage_desc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("n", C.c_int64), ("cin", C.c_int32), ("cout", C.c_int32), ("r", C.c_int32), ("_pad", C.c_int32),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("wt", C.c_void_p), ("bt", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("wf", C.c_void_p), ("bf", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64)]
+
+
 class pt_param_seg(C.Structure):
     _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("shadow_offset", C.c_int64),
                 ("layout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("frozen", C.c_int32)]
@@ -114,6 +120,7 @@ SIGNATURES = {
     "pt_rowconv": [C.POINTER(pt_rowconv_desc), _i32, _vp],
     "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],
     "pt_encodec_tail": [C.POINTER(pt_encodec_tail_desc), _i32, _vp],
+    "pt_encodec_stage": [C.POINTER(pt_encodec_stage_desc), _i32, _vp],
     "pt_codes_from_continuous": [_vp, _vp, _i64, _i64, _vp],
     "pt_sample_topk": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
 }
@@ -132,7 +139,7 @@ def _load():
     lib.pt_struct_size.argtypes = [C.c_int]
     lib.pt_wgrad_group_ws_floats.restype = C.c_int64
     lib.pt_wgrad_group_ws_floats.argtypes = [C.c_int]
-    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc)):
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc, pt_encodec_stage_desc)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():

@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 15; }
+extern "C" int pt_abi_version(void) { return 16; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
@@ -25,6 +25,7 @@ extern "C" int pt_struct_size(int which) {
     case 5: return (int)sizeof(pt_lstm2_desc);
     case 6: return (int)sizeof(pt_fold_seg);
     case 7: return (int)sizeof(pt_encodec_tail_desc);
+    case 8: return (int)sizeof(pt_encodec_stage_desc);
     default: return -1;
   }
 }

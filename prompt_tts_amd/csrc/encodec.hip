@@ -454,6 +454,16 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
 // and recomputes the halo's intermediates; all weights (30 MFMA B fragments) stay in registers for the whole kernel.
 // HBM-bound: 128 B read + 8 B written per input row.
 constexpr int TL_CIN = 64, TL_C = 32, TL_RIN = 64, TL_HALO = 5, TL_RI = 80, TL_RO = 160, TL_XSTRIDE = 144;
+// LDS row strides of the intermediates: an MFMA result puts 16 DIFFERENT rows on the 16 lanes of a store group, all at the same
+// column, so a 64-byte row stride (a divisor of the 128-byte store bank window) is a 16-way conflict on every ds_write_b64;
+// 72 / 40 bytes spread consecutive rows over all banks (fragments are then read as two 8-byte halves)
+constexpr int TL_S64 = 72, TL_S32 = 40;
+__device__ __forceinline__ bf16x8_t tl_frag(const char* p) {
+  typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+  const u2 lo = *reinterpret_cast<const u2*>(p), hi = *reinterpret_cast<const u2*>(p + 8);
+  const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
 struct TailParams {
   int B, n;                       // items, input rows per item (output: 2 n samples per item)
   const bf16_t* x; int64_t ldx;
@@ -466,12 +476,12 @@ struct TailParams {
 };
 
 __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[TL_RI * TL_XSTRIDE + 2 * TL_RO * 64 + TL_RO * 32 + TL_RO * 64];
+  __shared__ __attribute__((aligned(16))) char smem[TL_RI * TL_XSTRIDE + 3 * TL_RO * TL_S64 + TL_RO * TL_S32];
   char* Xin = smem;                                   // [80][144 B]: 64 channels + 16 B pad (bank spread)
   char* X1r = Xin + TL_RI * TL_XSTRIDE;               // [160][64 B] raw
-  char* X1e = X1r + TL_RO * 64;                       // [160][64 B] ELU
-  char* C3e = X1e + TL_RO * 64;                       // [160][32 B]
-  char* Oute = C3e + TL_RO * 32;                      // [160][64 B]
+  char* X1e = X1r + TL_RO * TL_S64;                       // [160][64 B] ELU
+  char* C3e = X1e + TL_RO * TL_S64;                       // [160][32 B]
+  char* Oute = C3e + TL_RO * TL_S32;                      // [160][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   // ---- weights -> registers (B-operand fragments: output channel 16 nt + li, k = 32 ks + 8 g + j) ----
   Frag<bf16_t> wt[4][4], w3[3], wf[2][2], wfin[7];
@@ -531,8 +541,8 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bf16_bits_to_f32(f32_to_bf16_bits(acc[nt][r] + bt4[nt][r]));   // the layer's bf16 output
-        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1r + orow * 64) + co, v[0], v[1], v[2], v[3]);
-        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + orow * 64) + co, elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3]));
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1r + orow * TL_S64) + co, v[0], v[1], v[2], v[3]);
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + orow * TL_S64) + co, elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3]));
       }
     }
     __syncthreads();
@@ -544,11 +554,11 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
       for (int tap = 0; tap < 3; ++tap) {
         const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
         Frag<bf16_t> fa;
-        if (sj >= 0 && sj < TL_RO) fa.v = *reinterpret_cast<const bf16x8_t*>(X1e + sj * 64 + 16 * g);
+        if (sj >= 0 && sj < TL_RO) fa.v = tl_frag(X1e + sj * TL_S64 + 16 * g);
         else frag_zero(fa);
         mma16(acc, w3[tap], fa);
       }
-      store4<bf16_t>(reinterpret_cast<bf16_t*>(C3e + j * 32) + 4 * g, elu_f(acc[0] + b34[0]), elu_f(acc[1] + b34[1]),
+      store4<bf16_t>(reinterpret_cast<bf16_t*>(C3e + j * TL_S32) + 4 * g, elu_f(acc[0] + b34[0]), elu_f(acc[1] + b34[1]),
                      elu_f(acc[2] + b34[2]), elu_f(acc[3] + b34[3]));
     }
     __syncthreads();
@@ -557,13 +567,13 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
       f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
       const int j = 16 * rt + li;
       Frag<bf16_t> f0, f1;
-      f0.v = *reinterpret_cast<const bf16x8_t*>(g < 2 ? C3e + j * 32 + 16 * g : X1r + j * 64 + 16 * (g - 2));   // k 0..15 | 16..31
-      if (g < 2) f1.v = *reinterpret_cast<const bf16x8_t*>(X1r + j * 64 + 32 + 16 * g); else frag_zero(f1);      // k 32..47 | pad
+      f0.v = tl_frag(g < 2 ? C3e + j * TL_S32 + 16 * g : X1r + j * TL_S64 + 16 * (g - 2));   // k 0..15 | 16..31
+      if (g < 2) f1.v = tl_frag(X1r + j * TL_S64 + 32 + 16 * g); else frag_zero(f1);      // k 32..47 | pad
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) { mma16(acc[nt], wf[nt][0], f0); mma16(acc[nt], wf[nt][1], f1); }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
-        store4<bf16_t>(reinterpret_cast<bf16_t*>(Oute + j * 64) + 16 * nt + 4 * g, elu_f(acc[nt][0] + bf4[nt][0]),
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(Oute + j * TL_S64) + 16 * nt + 4 * g, elu_f(acc[nt][0] + bf4[nt][0]),
                        elu_f(acc[nt][1] + bf4[nt][1]), elu_f(acc[nt][2] + bf4[nt][2]), elu_f(acc[nt][3] + bf4[nt][3]));
     }
     __syncthreads();
@@ -576,11 +586,160 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
       for (int tap = 0; tap < 7; ++tap) {
         const int v = t + tap - 6, sj = (v < 0 ? -v : v) - t_base;
         Frag<bf16_t> fa;
-        if (sj >= 0 && sj < TL_RO) fa.v = *reinterpret_cast<const bf16x8_t*>(Oute + sj * 64 + 16 * g);
+        if (sj >= 0 && sj < TL_RO) fa.v = tl_frag(Oute + sj * TL_S64 + 16 * g);
         else frag_zero(fa);
         mma16(acc, wfin[tap], fa);                                                // row 0 of D = the single output channel
       }
       if (g == 0 && j >= j_lo && j < j_lo + 2 * TL_RIN && t < n_out) p.wav[(int64_t)b * n_out + t] = acc[0] + bfin;
+    }
+  }
+}
+
+// ---- fused decoder stage 2 (bf16): transposed conv k8 s4 (128 -> 64) + residual block, one launch ---------------------------
+//   xe [B][n][128] (ELU'd, 3 kHz) -> x1 [B][4n][64] -> ELU -> causal conv k3 (64 -> 32) -> ELU -> 1x1 (32 -> 64) + 1x1 shortcut(x1)
+//   -> ELU -> out [B][4n][64] (12 kHz, the tail's input).
+// As three launches (one GEMM writing x1 raw + ELU'd, two row-streaming convs) this stage read / wrote 7.4 GB per 64 x 1024
+// frames for 0.67 GB of input and 1.34 GB of output.  A workgroup takes 30 input rows + a 2-row halo; wave w owns phase rho = w
+// of the transposed conv (its 32 weight fragments stay in registers), the two small weight matrices sit in LDS (row strides
+// 400 / 208 B: 16 rows land on 16 different 16-byte slots), intermediates in LDS at strides 136 / 72 B (see the tail kernel).
+constexpr int S2_CIN = 128, S2_C = 64, S2_RIN = 30, S2_HALO = 2, S2_RI = 32, S2_RO = 128;
+constexpr int S2_XS = 272, S2_S1 = 136, S2_S3 = 72, S2_W3S = 400, S2_WFS = 208;
+struct Stage2Params {
+  int B, n;
+  const bf16_t* x; int64_t ldx;
+  const bf16_t* wt; const float* bt;       // [256][256], [256]
+  const bf16_t* w3; const float* b3;       // [32][192],  [32]
+  const bf16_t* wf; const float* bf;       // [64][96],   [64]
+  bf16_t* y; int64_t ldy;
+  int tiles_per_item;
+};
+
+__global__ __launch_bounds__(256) void encodec_stage2_kernel(const Stage2Params p) {
+  __shared__ __attribute__((aligned(16))) char smem[S2_RI * S2_XS + 2 * S2_RO * S2_S1 + S2_RO * S2_S3 + 32 * S2_W3S + 64 * S2_WFS];
+  char* Xin = smem;
+  char* X1r = Xin + S2_RI * S2_XS;
+  char* X1e = X1r + S2_RO * S2_S1;
+  char* C3e = X1e + S2_RO * S2_S1;
+  char* W3s = C3e + S2_RO * S2_S3;
+  char* Wfs = W3s + 32 * S2_W3S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  // transposed-conv weights of this wave's phase: rows 64 wave + 16 nt + li, k = 32 ks + 8 g
+  Frag<bf16_t> wt[4][8];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) frag_load_global(wt[nt][ks], p.wt + (64 * wave + 16 * nt + li) * 256 + 32 * ks + 8 * g);
+  float bt4[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bt4[nt][r] = p.bt[64 * wave + 16 * nt + 4 * g + r];
+  for (int q = tid; q < 32 * 24; q += 256) { const int row = q / 24, ch = q - row * 24;
+    *reinterpret_cast<u32x4_t*>(W3s + row * S2_W3S + 16 * ch) = *reinterpret_cast<const u32x4_t*>(p.w3 + row * 192 + 8 * ch); }
+  for (int q = tid; q < 64 * 12; q += 256) { const int row = q / 12, ch = q - row * 12;
+    *reinterpret_cast<u32x4_t*>(Wfs + row * S2_WFS + 16 * ch) = *reinterpret_cast<const u32x4_t*>(p.wf + row * 96 + 8 * ch); }
+  float b34[2][4], bf4[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b34[nt][r] = p.b3[16 * nt + 4 * g + r];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf4[nt][r] = p.bf[16 * nt + 4 * g + r];
+  const int n_out = 4 * p.n;
+
+  for (int tile = blockIdx.x; tile < p.B * p.tiles_per_item; tile += gridDim.x) {
+    const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * S2_RIN;
+    const int ni0 = n0 >= S2_HALO ? n0 - S2_HALO : 0;
+    const int t_base = 4 * ni0;
+    __syncthreads();
+    for (int q = tid; q < S2_RI * 16; q += 256) {
+      const int i = q >> 4, ch = q & 15, nrow = ni0 + i;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (nrow < p.n) v = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b * p.n + nrow) * p.ldx + 8 * ch);
+      *reinterpret_cast<u32x4_t*>(Xin + i * S2_XS + 16 * ch) = v;
+    }
+    __syncthreads();
+    // ---- transposed conv: x1[4 i + rho][co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*64+co][tap*128+ci]; wave = rho ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4_t acc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int i = 16 * rt + li;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int src = i - (ks >> 2);
+        Frag<bf16_t> fa;
+        if (src >= 0) fa.v = *reinterpret_cast<const bf16x8_t*>(Xin + src * S2_XS + (ks & 3) * 64 + 16 * g);
+        else frag_zero(fa);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mma16(acc[nt], wt[nt][ks], fa);
+      }
+      const int orow = 4 * i + wave;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bf16_bits_to_f32(f32_to_bf16_bits(acc[nt][r] + bt4[nt][r]));
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1r + orow * S2_S1) + 16 * nt + 4 * g, v[0], v[1], v[2], v[3]);
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + orow * S2_S1) + 16 * nt + 4 * g, elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3]));
+      }
+    }
+    __syncthreads();
+    // ---- c3e[j] = ELU(b3 + conv k3 over ELU(x1)) ----
+    for (int rt = wave; rt < S2_RO / 16; rt += 4) {
+      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+      const int j = 16 * rt + li, t = t_base + j;
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
+        const bool ok = sj >= 0 && sj < S2_RO;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          Frag<bf16_t> fa;
+          if (ok) fa.v = tl_frag(X1e + sj * S2_S1 + 64 * kk + 16 * g); else frag_zero(fa);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            Frag<bf16_t> wb;
+            wb.v = *reinterpret_cast<const bf16x8_t*>(W3s + (16 * nt + li) * S2_W3S + (tap * 64 + 32 * kk + 8 * g) * 2);
+            mma16(acc[nt], wb, fa);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(C3e + j * S2_S3) + 16 * nt + 4 * g, elu_f(acc[nt][0] + b34[nt][0]),
+                       elu_f(acc[nt][1] + b34[nt][1]), elu_f(acc[nt][2] + b34[nt][2]), elu_f(acc[nt][3] + b34[nt][3]));
+    }
+    __syncthreads();
+    // ---- out[j] = ELU(bf + Wf [c3e[j] (32) | x1[j] (64)]) -> HBM (only this tile's own 120 rows) ----
+    const int j_lo = 4 * (n0 - ni0);
+    for (int rt = wave; rt < S2_RO / 16; rt += 4) {
+      f32x4_t acc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int j = 16 * rt + li, t = t_base + j;
+      Frag<bf16_t> fa[3];
+      fa[0].v = tl_frag(C3e + j * S2_S3 + 16 * g);
+      fa[1].v = tl_frag(X1r + j * S2_S1 + 16 * g);
+      fa[2].v = tl_frag(X1r + j * S2_S1 + 64 + 16 * g);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          Frag<bf16_t> wb;
+          wb.v = *reinterpret_cast<const bf16x8_t*>(Wfs + (16 * nt + li) * S2_WFS + (32 * ks + 8 * g) * 2);
+          mma16(acc[nt], wb, fa[ks]);
+        }
+      if (j >= j_lo && j < j_lo + 4 * S2_RIN && t < n_out) {
+        bf16_t* yp = p.y + ((int64_t)b * n_out + t) * p.ldy + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          store4<bf16_t>(yp + 16 * nt, elu_f(acc[nt][0] + bf4[nt][0]), elu_f(acc[nt][1] + bf4[nt][1]), elu_f(acc[nt][2] + bf4[nt][2]),
+                         elu_f(acc[nt][3] + bf4[nt][3]));
+      }
     }
   }
 }
@@ -695,6 +854,25 @@ extern "C" int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stre
   int64_t tiles = (int64_t)p.B * p.tiles_per_item;
   const unsigned grid = (unsigned)(tiles < 256 * 3 * 8 ? tiles : 256 * 3 * 8);
   hipLaunchKernelGGL(encodec_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_stream stream) {
+  if (!d) return PT_ERR_ARG;
+  if (dtype != PT_BF16) return PT_ERR_DTYPE;
+  if (d->B <= 0 || d->n < 4 || d->cin != S2_CIN || d->cout != S2_C || d->r != 4 || d->B * d->n >= (1ll << 29)) return PT_ERR_SHAPE;
+  if (!d->x || !d->wt || !d->bt || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->y) return PT_ERR_ARG;
+  if (!pt_aligned16(d->x) || (d->ldx * 2) % 16 || !pt_aligned16(d->wt) || !pt_aligned16(d->w3) || !pt_aligned16(d->wf) ||
+      (reinterpret_cast<uintptr_t>(d->y) & 7u) || d->ldy % 4) return PT_ERR_ALIGN;
+  Stage2Params p;
+  p.B = (int)d->B; p.n = (int)d->n; p.x = (const bf16_t*)d->x; p.ldx = d->ldx;
+  p.wt = (const bf16_t*)d->wt; p.bt = d->bt; p.w3 = (const bf16_t*)d->w3; p.b3 = d->b3; p.wf = (const bf16_t*)d->wf; p.bf = d->bf;
+  p.y = (bf16_t*)d->y; p.ldy = d->ldy;
+  p.tiles_per_item = (int)((d->n + S2_RIN - 1) / S2_RIN);
+  const int64_t tiles = (int64_t)p.B * p.tiles_per_item;
+  const unsigned grid = (unsigned)(tiles < 256 * 2 * 8 ? tiles : 256 * 2 * 8);
+  hipLaunchKernelGGL(encodec_stage2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }

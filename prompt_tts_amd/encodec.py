@@ -63,6 +63,7 @@ def _pad_cols(m, mult):
 
 
 FUSED_TAIL = __import__("os").environ.get("PT_ENCODEC_FUSED_TAIL", "1") != "0"
+FUSED_STAGES = __import__("os").environ.get("PT_ENCODEC_FUSED_STAGES", "1") != "0"
 
 
 class EncodecDecoder:
@@ -158,6 +159,17 @@ class EncodecDecoder:
                 td.wav = wav.data_ptr()
                 check(lib.pt_encodec_tail(C.byref(td), pt, ops._stream()), "pt_encodec_tail")
                 return wav.view(B, 1, n * r)
+            if self.dtype == torch.bfloat16 and FUSED_STAGES and (r, cin, cout) == (4, 128, 64) and n >= 4:
+                # transposed conv + residual block of the 3 kHz -> 12 kHz stage in one launch
+                oute = self._empty(B * n * r, cout)
+                sd = L.pt_encodec_stage_desc()
+                sd.B, sd.n, sd.cin, sd.cout, sd.r = B, n, cin, cout, r
+                sd.x, sd.ldx = xe.data_ptr(), xe.stride(0)
+                sd.wt, sd.bt, sd.w3, sd.b3 = st["wt"].data_ptr(), st["bt"].data_ptr(), st["w3"].data_ptr(), st["b3"].data_ptr()
+                sd.wf, sd.bf, sd.y, sd.ldy = st["wf"].data_ptr(), st["bf"].data_ptr(), oute.data_ptr(), oute.stride(0)
+                check(lib.pt_encodec_stage(C.byref(sd), pt, ops._stream()), "pt_encodec_stage")
+                xe, n = oute, n * r
+                continue
             Min, Mout, n_out = B * n, B * n * r, n * r
             x1 = self._empty(Min, r * cout)
             x1e = None

@@ -97,20 +97,26 @@ def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, monkeypat
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T", [(1, 7), (3, 33), (2, 101)])
 def test_fused_24khz_tail_equals_the_separate_launches(dev, B, T, monkeypatch):
-    """pt_encodec_tail (last transposed conv + residual block + final conv in one launch, intermediates in LDS) against the
-    four row-streaming launches it replaces, same bf16 rounding points: item starts (reflect padding), tile seams (64-row
+    """pt_encodec_tail (last transposed conv + residual block + final conv in one launch, intermediates in LDS) and
+    pt_encodec_stage (the 3 kHz -> 12 kHz stage: transposed conv + residual block in one launch) against the seven separate
+    launches they replace, same bf16 rounding points: item starts (reflect padding), tile seams (64-row
     tiles + 5-row halo; 33 and 101 frames are not multiples of anything) and item ends."""
     import prompt_tts_amd.encodec as pe
     from oracle import encodec as oe
     dec = pe.EncodecDecoder(oe.random_weights(8), device=dev, dtype=torch.bfloat16)
     codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(T)).to(dev)
-    monkeypatch.setattr(pe, "FUSED_TAIL", True)
+    monkeypatch.setattr(pe, "FUSED_TAIL", True); monkeypatch.setattr(pe, "FUSED_STAGES", True)
     fused = dec.decode(codes).cpu()
+    monkeypatch.setattr(pe, "FUSED_STAGES", False)
+    tail_only = dec.decode(codes).cpu()
     monkeypatch.setattr(pe, "FUSED_TAIL", False)
     sep = dec.decode(codes).cpu()
+    assert float((tail_only - sep).abs().max()) < 4e-3 * float(sep.abs().max())
     assert fused.shape == sep.shape == (B, 1, 320 * T)
     peak = float(sep.abs().max())
-    assert float((fused - sep).abs().max()) < 4e-3 * peak, float((fused - sep).abs().max()) / peak     # same roundings, other summation order
+    # same bf16 rounding points, other summation orders inside the two fused kernels (bf16 eps = 3.9e-3 per rounding)
+    assert float((fused - sep).abs().max()) < 1e-2 * peak, float((fused - sep).abs().max()) / peak
+    assert float((fused - sep).pow(2).mean().sqrt()) < 2e-3 * peak
     want = oe.decode(codes.cpu(), oe.random_weights(8))
     assert float((fused - want).abs().max()) < 6e-2 * float(want.abs().max())
 
