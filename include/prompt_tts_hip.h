@@ -345,6 +345,10 @@ typedef struct pt_encodec_stage_desc {
   void* y; int64_t ldy;
 } pt_encodec_stage_desc;
 int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_stream stream);
+/* Fused residual block alone (bf16, cin = cout = 128, r = 1; wt / bt unused): x = RAW output rows [B*n][ldx] of the stage's
+ * transposed conv, y = ELU(1x1([ELU(conv k3(ELU(x))) | x])) -- the residual block of the 600 Hz -> 3 kHz stage, whose transposed
+ * conv (640 x 512 weights) stays a pt_gemm. */
+int pt_encodec_res(const pt_encodec_stage_desc* d, int dtype, pt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.

@@ -121,6 +121,7 @@ SIGNATURES = {
     "pt_lstm2_forward": [C.POINTER(pt_lstm2_desc), _i32, _vp],
     "pt_encodec_tail": [C.POINTER(pt_encodec_tail_desc), _i32, _vp],
     "pt_encodec_stage": [C.POINTER(pt_encodec_stage_desc), _i32, _vp],
+    "pt_encodec_res": [C.POINTER(pt_encodec_stage_desc), _i32, _vp],
     "pt_codes_from_continuous": [_vp, _vp, _i64, _i64, _vp],
     "pt_sample_topk": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
 }

@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 16; }
+extern "C" int pt_abi_version(void) { return 17; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {

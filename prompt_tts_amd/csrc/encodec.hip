@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void encodec_stage2_kernel(const Stage2Params 
       f32x4_t acc[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const int j = 16 * rt + li, t = t_base + j;
+      const int j = 16 * rt + li;
       Frag<bf16_t> fa[3];
       fa[0].v = tl_frag(C3e + j * S2_S3 + 16 * g);
       fa[1].v = tl_frag(X1r + j * S2_S1 + 16 * g);
@@ -733,13 +733,121 @@ __global__ __launch_bounds__(256) void encodec_stage2_kernel(const Stage2Params 
           wb.v = *reinterpret_cast<const bf16x8_t*>(Wfs + (16 * nt + li) * S2_WFS + (32 * ks + 8 * g) * 2);
           mma16(acc[nt], wb, fa[ks]);
         }
-      if (j >= j_lo && j < j_lo + 4 * S2_RIN && t < n_out) {
-        bf16_t* yp = p.y + ((int64_t)b * n_out + t) * p.ldy + 4 * g;
+      // staged in LDS over the dead ELU copy (last read by the k3 conv above), so that HBM sees whole 128-byte rows
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          store4<bf16_t>(yp + 16 * nt, elu_f(acc[nt][0] + bf4[nt][0]), elu_f(acc[nt][1] + bf4[nt][1]), elu_f(acc[nt][2] + bf4[nt][2]),
-                         elu_f(acc[nt][3] + bf4[nt][3]));
+      for (int nt = 0; nt < 4; ++nt)
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + j * S2_S1) + 16 * nt + 4 * g, elu_f(acc[nt][0] + bf4[nt][0]),
+                       elu_f(acc[nt][1] + bf4[nt][1]), elu_f(acc[nt][2] + bf4[nt][2]), elu_f(acc[nt][3] + bf4[nt][3]));
+    }
+    __syncthreads();
+    for (int q = tid; q < 4 * S2_RIN * 8; q += 256) {
+      const int i = q >> 3, ch = q & 7, t = 4 * n0 + i;
+      if (t < n_out) {
+        const bf16x8_t v = tl_frag(X1e + (j_lo + i) * S2_S1 + 16 * ch);
+        *reinterpret_cast<bf16x8_t*>(p.y + ((int64_t)b * n_out + t) * p.ldy + 8 * ch) = v;
       }
+    }
+  }
+}
+
+// ---- fused residual block of the 600 Hz -> 3 kHz stage (bf16, 128 channels) -------------------------------------------------
+//   x1 [B][n][128] (raw output of the stage's transposed conv) -> ELU -> causal conv k3 (128 -> 64) -> ELU -> 1x1 (64 -> 128) +
+//   1x1 shortcut(x1) -> ELU -> out [B][n][128].
+// As two GEMM launches (plus the transposed conv writing x1 twice, raw and ELU'd) this block moved 3.7 GB per 64 x 1024 frames for
+// 0.67 GB in + 0.67 GB out.  A workgroup takes 62 rows + a 2-row halo; wave w owns 16 of the 64 k3 output channels and 32 of
+// the 128 block outputs with ALL their weight fragments in registers (24 fragments), so LDS carries activations only; the output
+// tile is staged in LDS (over the dead ELU copy) and leaves as whole 256-byte rows.
+constexpr int R1_C = 128, R1_ROWS = 64, R1_OWN = 62, R1_XS = 272, R1_S3 = 136;
+struct Res1Params {
+  int B, n;
+  const bf16_t* x; int64_t ldx;
+  const bf16_t* w3; const float* b3;       // [64][384],  [64]
+  const bf16_t* wf; const float* bf;       // [128][192], [128]
+  bf16_t* y; int64_t ldy;
+  int tiles_per_item;
+};
+
+__global__ __launch_bounds__(256) void encodec_res1_kernel(const Res1Params p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * R1_ROWS * R1_XS + R1_ROWS * R1_S3];
+  char* X1r = smem;
+  char* X1e = X1r + R1_ROWS * R1_XS;                  // ELU(x1); reused for the output tile
+  char* C3e = X1e + R1_ROWS * R1_XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  Frag<bf16_t> w3[12], wf[2][6];
+#pragma unroll
+  for (int ks = 0; ks < 12; ++ks) frag_load_global(w3[ks], p.w3 + (16 * wave + li) * 384 + 32 * ks + 8 * g);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) frag_load_global(wf[nt][ks], p.wf + (32 * wave + 16 * nt + li) * 192 + 32 * ks + 8 * g);
+  float b34[4], bf4[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b34[r] = p.b3[16 * wave + 4 * g + r];
+    bf4[0][r] = p.bf[32 * wave + 4 * g + r]; bf4[1][r] = p.bf[32 * wave + 16 + 4 * g + r];
+  }
+
+  for (int tile = blockIdx.x; tile < p.B * p.tiles_per_item; tile += gridDim.x) {
+    const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * R1_OWN;
+    const int t_base = n0 >= 2 ? n0 - 2 : 0;
+    __syncthreads();
+    for (int q = tid; q < R1_ROWS * 16; q += 256) {
+      const int i = q >> 4, ch = q & 15, row = t_base + i;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (row < p.n) v = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b * p.n + row) * p.ldx + 8 * ch);
+      *reinterpret_cast<u32x4_t*>(X1r + i * R1_XS + 16 * ch) = v;
+      u32x4_t e;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = elu_f(bf16_bits_to_f32((uint16_t)(v[k] & 0xffffu))), hi = elu_f(bf16_bits_to_f32((uint16_t)(v[k] >> 16)));
+        e[k] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+      }
+      *reinterpret_cast<u32x4_t*>(X1e + i * R1_XS + 16 * ch) = e;
+    }
+    __syncthreads();
+    // ---- c3e[j][16 w ..] = ELU(b3 + conv k3 over ELU(x1), causal with reflect at the item start) ----
+#pragma unroll
+    for (int rt = 0; rt < R1_ROWS / 16; ++rt) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int j = 16 * rt + li, t = t_base + j;
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
+        const bool ok = sj >= 0 && sj < R1_ROWS;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          Frag<bf16_t> fa;
+          if (ok) fa.v = *reinterpret_cast<const bf16x8_t*>(X1e + sj * R1_XS + 64 * kk + 16 * g); else frag_zero(fa);
+          mma16(acc, w3[4 * tap + kk], fa);
+        }
+      }
+      store4<bf16_t>(reinterpret_cast<bf16_t*>(C3e + j * R1_S3) + 16 * wave + 4 * g, elu_f(acc[0] + b34[0]), elu_f(acc[1] + b34[1]),
+                     elu_f(acc[2] + b34[2]), elu_f(acc[3] + b34[3]));
+    }
+    __syncthreads();
+    // ---- out[j][32 w ..] = ELU(bf + Wf [c3e[j] (64) | x1[j] (128)]) -> LDS (over X1e) ----
+#pragma unroll
+    for (int rt = 0; rt < R1_ROWS / 16; ++rt) {
+      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+      const int j = 16 * rt + li;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        Frag<bf16_t> fa;
+        if (ks < 2) fa.v = tl_frag(C3e + j * R1_S3 + 64 * ks + 16 * g);
+        else fa.v = *reinterpret_cast<const bf16x8_t*>(X1r + j * R1_XS + 64 * (ks - 2) + 16 * g);
+        mma16(acc[0], wf[0][ks], fa); mma16(acc[1], wf[1][ks], fa);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + j * R1_XS) + 32 * wave + 16 * nt + 4 * g, elu_f(acc[nt][0] + bf4[nt][0]),
+                       elu_f(acc[nt][1] + bf4[nt][1]), elu_f(acc[nt][2] + bf4[nt][2]), elu_f(acc[nt][3] + bf4[nt][3]));
+    }
+    __syncthreads();
+    const int j_lo = n0 - t_base;
+    for (int q = tid; q < R1_OWN * 16; q += 256) {
+      const int i = q >> 4, ch = q & 15, t = n0 + i;
+      if (t < p.n)
+        *reinterpret_cast<u32x4_t*>(p.y + ((int64_t)b * p.n + t) * p.ldy + 8 * ch) = *reinterpret_cast<const u32x4_t*>(X1e + (j_lo + i) * R1_XS + 16 * ch);
     }
   }
 }
@@ -864,7 +972,7 @@ extern "C" int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_st
   if (d->B <= 0 || d->n < 4 || d->cin != S2_CIN || d->cout != S2_C || d->r != 4 || d->B * d->n >= (1ll << 29)) return PT_ERR_SHAPE;
   if (!d->x || !d->wt || !d->bt || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->y) return PT_ERR_ARG;
   if (!pt_aligned16(d->x) || (d->ldx * 2) % 16 || !pt_aligned16(d->wt) || !pt_aligned16(d->w3) || !pt_aligned16(d->wf) ||
-      (reinterpret_cast<uintptr_t>(d->y) & 7u) || d->ldy % 4) return PT_ERR_ALIGN;
+      !pt_aligned16(d->y) || d->ldy % 8) return PT_ERR_ALIGN;
   Stage2Params p;
   p.B = (int)d->B; p.n = (int)d->n; p.x = (const bf16_t*)d->x; p.ldx = d->ldx;
   p.wt = (const bf16_t*)d->wt; p.bt = d->bt; p.w3 = (const bf16_t*)d->w3; p.b3 = d->b3; p.wf = (const bf16_t*)d->wf; p.bf = d->bf;
@@ -873,6 +981,25 @@ extern "C" int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_st
   const int64_t tiles = (int64_t)p.B * p.tiles_per_item;
   const unsigned grid = (unsigned)(tiles < 256 * 2 * 8 ? tiles : 256 * 2 * 8);
   hipLaunchKernelGGL(encodec_stage2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_encodec_res(const pt_encodec_stage_desc* d, int dtype, pt_stream stream) {
+  if (!d) return PT_ERR_ARG;
+  if (dtype != PT_BF16) return PT_ERR_DTYPE;
+  if (d->B <= 0 || d->n < 3 || d->cin != R1_C || d->cout != R1_C || d->r != 1 || d->B * d->n >= (1ll << 30)) return PT_ERR_SHAPE;
+  if (!d->x || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->y) return PT_ERR_ARG;
+  if (!pt_aligned16(d->x) || (d->ldx * 2) % 16 || !pt_aligned16(d->w3) || !pt_aligned16(d->wf) || !pt_aligned16(d->y) || (d->ldy * 2) % 16)
+    return PT_ERR_ALIGN;
+  Res1Params p;
+  p.B = (int)d->B; p.n = (int)d->n; p.x = (const bf16_t*)d->x; p.ldx = d->ldx;
+  p.w3 = (const bf16_t*)d->w3; p.b3 = d->b3; p.wf = (const bf16_t*)d->wf; p.bf = d->bf;
+  p.y = (bf16_t*)d->y; p.ldy = d->ldy;
+  p.tiles_per_item = (int)((d->n + R1_OWN - 1) / R1_OWN);
+  const int64_t tiles = (int64_t)p.B * p.tiles_per_item;
+  const unsigned grid = (unsigned)(tiles < 256 * 3 * 4 ? tiles : 256 * 3 * 4);
+  hipLaunchKernelGGL(encodec_res1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }

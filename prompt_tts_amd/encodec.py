@@ -173,6 +173,18 @@ class EncodecDecoder:
             Min, Mout, n_out = B * n, B * n * r, n * r
             x1 = self._empty(Min, r * cout)
             x1e = None
+            if self.dtype == torch.bfloat16 and FUSED_STAGES and cout == 128 and not st["small_up"] and n_out >= 3:
+                # transposed conv as a GEMM (its 640 x 512 weights do not fit a CU), then the whole residual block in one launch
+                ops.gemm(Min, r * cout, 2 * cin, ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2), ops.plain(st["wt"]), x1, pt, bias=st["bt"])
+                oute = self._empty(Mout, cout)
+                sd = L.pt_encodec_stage_desc()
+                sd.B, sd.n, sd.cin, sd.cout, sd.r = B, n_out, cout, cout, 1
+                sd.x, sd.ldx = x1.data_ptr(), cout
+                sd.w3, sd.b3, sd.wf, sd.bf = st["w3"].data_ptr(), st["b3"].data_ptr(), st["wf"].data_ptr(), st["bf"].data_ptr()
+                sd.y, sd.ldy = oute.data_ptr(), oute.stride(0)
+                check(lib.pt_encodec_res(C.byref(sd), pt, ops._stream()), "pt_encodec_res")
+                xe, n = oute, n_out
+                continue
             if st["small_up"]:
                 self._rowconv(B, n, xe, cin, 2, L.PT_MAP_BACK, st["wt"], st["bt"], r * cout, x1)
             else:

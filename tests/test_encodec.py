@@ -98,8 +98,8 @@ def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, monkeypat
 @pytest.mark.parametrize("B,T", [(1, 7), (3, 33), (2, 101)])
 def test_fused_24khz_tail_equals_the_separate_launches(dev, B, T, monkeypatch):
     """pt_encodec_tail (last transposed conv + residual block + final conv in one launch, intermediates in LDS) and
-    pt_encodec_stage (the 3 kHz -> 12 kHz stage: transposed conv + residual block in one launch) against the seven separate
-    launches they replace, same bf16 rounding points: item starts (reflect padding), tile seams (64-row
+    pt_encodec_stage (the 3 kHz -> 12 kHz stage: transposed conv + residual block in one launch) and pt_encodec_res (the
+    residual block of the 600 Hz -> 3 kHz stage, 62-row tiles + 2-row halo) against the separate launches they replace, same bf16 rounding points: item starts (reflect padding), tile seams (64-row
     tiles + 5-row halo; 33 and 101 frames are not multiples of anything) and item ends."""
     import prompt_tts_amd.encodec as pe
     from oracle import encodec as oe
