@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md:42-43
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 2500.0}   # "fp8" = bf16 step with a few fp8 GEMMs: priced at bf16      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md:42-43
 WORKLOADS = {   # BASELINE.json configs -> 1d_config
     "A": dict(d=256, L=1, text_layers=1, n_q=2, T=1024, B=4),
     "B": dict(d=512, L=5, text_layers=2, n_q=8, T=1024, B=32),
@@ -253,7 +253,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = bf16 with fp8-operand feed-forward GEMMs (workload E, BASELINE configs[4]); never the default")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the Encodec decode leg (audio-s/s)")
@@ -287,9 +288,9 @@ def main():
         wl["B"] = args.batch
     S = 256
     cfg = make_config(wl["d"], wl["L"], wl["text_layers"], wl["n_q"], wl["T"], S)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)                                   # identical replicas on every rank (DDP's C1 broadcast)
-    model = TTSSingleSpeaker(cfg, dtype=dtype).to(dev)
+    model = TTSSingleSpeaker(cfg, dtype=dtype, fp8=args.dtype == "fp8").to(dev)
     st = model.store
     reducer = parallel.attach(model) if world > 1 else None
     batch = [x.to(dev) for x in synthetic_batch(wl["B"], wl["n_q"], wl["T"], S, 1234 + rank)]
@@ -355,7 +356,10 @@ def main():
         # gradient kernel (the kernel the round-1 review named); "roofline_step" = the aggregate of all launches of one step
         captured = []
         kern = ops.profile_one_step(step, capture=captured)
-        mf = {k: v for k, v in kern.items() if "tflops" in v and (k.startswith("gemm<" + args.dtype) or k.startswith("wgrad_group"))}
+        mf = {k: v for k, v in kern.items() if "tflops" in v and (k.startswith("gemm<" + ("bf16" if args.dtype == "fp8" else args.dtype)) or k.startswith("wgrad_group"))}
+        if args.dtype == "fp8":
+            out["fp8_gemms"] = {k: dict(v, frac_of_fp8_peak=v["tflops"] / 5000.0) for k, v in kern.items() if k.startswith("gemm_fp8") and "tflops" in v}
+            out["fp8_quantize"] = kern.get("pt_fp8_quantize")
         pmc = None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):

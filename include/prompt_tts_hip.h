@@ -28,6 +28,7 @@ typedef void* pt_stream;            /* a hipStream_t */
 enum pt_status { PT_OK = 0, PT_ERR_SHAPE = -1, PT_ERR_DTYPE = -2, PT_ERR_LAUNCH = -3, PT_ERR_ALIGN = -4,
                  PT_ERR_ARG = -5 };
 enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
+enum pt_fp8_format { PT_FP8_E4M3 = 0, PT_FP8_E5M2 = 1 };   /* OCP fp8: e4m3 "fn" (max 448), e5m2 (max 57344) */
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
@@ -349,6 +350,22 @@ int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_stream stream
  * transposed conv, y = ELU(1x1([ELU(conv k3(ELU(x))) | x])) -- the residual block of the 600 Hz -> 3 kHz stage, whose transposed
  * conv (640 x 512 weights) stays a pt_gemm. */
 int pt_encodec_res(const pt_encodec_stage_desc* d, int dtype, pt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp8 GEMMs (BASELINE configs[4], "fp8 MFMA GEMMs"): the forward and data-gradient GEMMs of the transformer's nn.Linear layers
+ * with fp8 operands (v_mfma_f32_16x16x128_f8f6f4), f32 accumulation, bf16 output; per-tensor scales stay on the device.
+ * ---------------------------------------------------------------------------------------------- */
+#define PT_FP8_AMAX_BLOCKS 256
+#define PT_FP8_STATE_FLOATS 258           /* {amax, scale, PT_FP8_AMAX_BLOCKS partial maxima (scratch)} */
+/* Quantise a bf16 matrix x [rows][ldx] (cols % 16 == 0): state[0] = amax |x|, state[1] = scale = amax / FMAX (1 if amax == 0),
+ * state (PT_FP8_STATE_FLOATS floats, no initialisation needed) also holds the reduction's scratch; out [rows][ld_out] = fp8(clamp(x / scale)) (round to nearest even).  out_t (may be NULL; needs rows, cols % 64 == 0) receives the
+ * transpose [cols][ld_t] as well (weights: the dgrad GEMM reads W^T with the reduction index contiguous). */
+int pt_fp8_quantize(const void* x, int64_t rows, int64_t cols, int64_t ldx, void* out, int64_t ld_out, void* out_t, int64_t ld_t,
+                    float* state, int format, pt_stream stream);
+/* C = (scale_a[0] * scale_b[0]) * A B^T (+ every store epilogue of pt_gemm: bias, residuals, act 1/2/3, C2): A [M][K] fp8 in
+ * `a_format`, B [N][K] fp8 e4m3, both PT_V_PLAIN and not transposed (ld in elements = bytes), K % 16 == 0; C bf16.  alpha of the
+ * descriptor still applies.  256 x 256 tiles on the eight-phase pipeline of pt_gemm; meant for M N >= ~128 tiles. */
+int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* scale_a, const float* scale_b, pt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * north_star ops with NO reference implementation (SURVEY 8a'): build-defined, pinned to torch / numpy in tests.

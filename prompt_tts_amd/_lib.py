@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
 
 PT_F32, PT_BF16 = 0, 1
+PT_FP8_E4M3, PT_FP8_E5M2 = 0, 1
+PT_FP8_STATE_FLOATS = 258
 PT_V_PLAIN, PT_V_CONCAT, PT_V_CONV, PT_V_WFLIP = 0, 1, 2, 3
 PT_MAP_S1, PT_MAP_S2, PT_MAP_UP2, PT_MAP_S2_DGRAD, PT_MAP_CAUSAL_REFLECT, PT_MAP_BACK, PT_MAP_STRIDED_REFLECT = 0, 1, 2, 3, 4, 5, 6
 PT_OUT_T, PT_OUT_F32, PT_OUT_F32_ATOMIC = 0, 1, 2
@@ -85,6 +87,8 @@ _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 SIGNATURES = {
     "pt_gemm": [C.POINTER(pt_gemm_desc), _i32, _vp],
     "pt_wgrad_group": [C.POINTER(pt_gemm_desc), _i32, _vp, _i64, _i32, _vp],
+    "pt_gemm_fp8": [C.POINTER(pt_gemm_desc), _i32, _vp, _vp, _vp],
+    "pt_fp8_quantize": [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp],
     "pt_attn_fwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_attn_bwd": [C.POINTER(pt_attn_desc), _i32, _vp],
     "pt_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],

@@ -52,7 +52,9 @@ struct GemmParams {
   float* arow_sum; int64_t arow_n, arow_stride; int arow_rep;
   int tiles_m, tiles_n;
   int64_t geglu_rows;          // pt_wgrad_group: > 0 = the GEMM's rows are GEGLU-interleaved weight rows (F = geglu_rows)
+  const float* scale_a; const float* scale_b;   // pt_gemm_fp8: device-resident dequantisation factors of the two operands
 };
+struct f8_t { uint8_t bits; };   // one fp8 operand element (e4m3 or e5m2): addressing only
 
 __device__ __attribute__((aligned(256))) const uint32_t pt_zero_page[64] = {0};
 
@@ -625,11 +627,17 @@ constexpr int P8_UNIT = 16384, P8_BUF = 4 * P8_UNIT, P8_THREADS = 512;
 // OUT: 0 = store epilogue (bias / residual / activation), 1 = f32 atomics into C, 2 = SLAB: the workgroup's raw 256 x 256 f32
 // partial tile goes to `slab` with whole-wave 1 KiB stores (pt_wgrad_group: split-K partials summed by wgrad_fold_kernel).
 // `bid` is the workgroup's index inside its problem: tiles x split_k, K-slice major.
-template <bool TA, bool TB, int OUT, int KA, int KB>
+// F8: 0 = bf16 operands; 1 / 2 = fp8 operands, K-contiguous (no transposed images), B (the weights) e4m3 and A (activations
+// / output gradients) e4m3 (1) or e5m2 (2): a k-tile is 128 elements -- the same 128-byte rows, unit images, swizzle and
+// staging schedule -- and the two 16-byte fragment reads of a row feed ONE v_mfma_f32_16x16x128_f8f6f4 instead of two
+// 16x16x32 bf16 MFMAs.  Which k a byte of a fragment stands for is irrelevant as long as both operands are read alike.
+template <bool TA, bool TB, int OUT, int KA, int KB, int F8 = 0>
 __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, float* __restrict__ slab, char* smem) {
   using T = bf16_t;
+  using TO = typename std::conditional<F8 != 0, f8_t, bf16_t>::type;     // operand element (addressing)
+  static_assert(F8 == 0 || (!TA && !TB && OUT == 0), "fp8 operands: K-contiguous, store epilogue");
   constexpr bool ATOMIC = OUT == 1;            // accumulator orientation D[row = m][col = n] (contiguous n per atomic)
-  constexpr int BM = 256, BN = 256, BK = 64, EPC = 8;
+  constexpr int BM = 256, BN = 256, BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -694,11 +702,11 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
         if (!TR) {
           const int u = q >> 3, c = (q & 7) ^ (u & 7);
           const int trow = OPER == 0 ? ((u >> 6) * 128 + S * 64 + (u & 63)) : ((u >> 5) * 64 + S * 32 + (u & 31));
-          ptr[U][i] = vaddr<T, KC>(op, t0 + trow, k0 + c * EPC);
+          ptr[U][i] = vaddr<TO, KC>(op, t0 + trow, k0 + c * EPC);
         } else {
           const int k = q >> 4, uc = ((q & 15) ^ tilet_swz(k)) * EPC;
           const int tcol = OPER == 0 ? ((uc >> 6) * 128 + S * 64 + (uc & 63)) : ((uc >> 5) * 64 + S * 32 + (uc & 31));
-          ptr[U][i] = vaddr<T, KC>(op, k0 + k, t0 + tcol);
+          ptr[U][i] = vaddr<TO, KC>(op, k0 + k, t0 + tcol);
         }
         stp[U][i] = ptr[U][i] == zero_page ? 0u : (uint32_t)op.step;
       }
@@ -767,6 +775,21 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (F8) {
+      typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+      auto cat = [](const Frag<T>& lo, const Frag<T>& hi) {
+        const u32x4_t a = __builtin_bit_cast(u32x4_t, lo.v), b = __builtin_bit_cast(u32x4_t, hi.v);
+        return (i32x8_t){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const i32x8_t a8 = cat(fa[i][0], fa[i][1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)      // D[row = n][col = m]: srcA = weights (e4m3), srcB = activations (blgp: 0 e4m3, 1 e5m2)
+          acc[4 * SA + i][2 * SB + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              cat(fb[j][0], fb[j][1]), a8, acc[4 * SA + i][2 * SB + j], 0, F8 == 2 ? 1 : 0, 0, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -776,6 +799,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
           if (ATOMIC) mma16(acc[4 * SA + i][2 * SB + j], fa[i][ks], fb[j][ks]);   // D[row = m][col = n]
           else        mma16(acc[4 * SA + i][2 * SB + j], fb[j][ks], fa[i][ks]);   // D[row = n][col = m]
         }
+    }
     if (OUT == 2 && SB == 0 && do_sum) {       // phases 0 and 3: every column of the product is sum_k A[m][k]
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -857,6 +881,13 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     }
     return;
   }
+  if (F8) {                               // per-tensor dequantisation: the product of the operands' device-resident factors
+    const float sc = p.scale_a[0] * p.scale_b[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
+  }
   gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * SCRATCH_PER_WAVE);
 }
 
@@ -870,6 +901,12 @@ template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];     // the ONLY LDS object (epilogue scratch aliases it)
   gemm8p_body<TA, TB, ATOMIC ? 1 : 0, KA, KB>(p, xcd_contiguous_id(blockIdx.x, gridDim.x), nullptr, smem);
+}
+
+template <int F8>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_f8_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];
+  gemm8p_body<false, false, 0, 0, 0, F8>(p, xcd_contiguous_id(blockIdx.x, gridDim.x), nullptr, smem);
 }
 
 // =====================================================================================================================
@@ -1061,10 +1098,11 @@ int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
 }
 
 // descriptor checks + conversion shared by pt_gemm and pt_wgrad_group
-static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p) {
+static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int operand_es = 0) {
   if (!d) return PT_ERR_ARG;
   if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
-  const int es = dtype == PT_F32 ? 4 : 2;
+  const int oes_t = dtype == PT_F32 ? 4 : 2;                 // output / residual element size
+  const int es = operand_es > 0 ? operand_es : oes_t;        // operand element size (1: fp8 operands, bf16 output)
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return PT_ERR_SHAPE;
   if (d->M >= (1ll << 31) || d->N >= (1ll << 31) || d->K >= (1ll << 31)) return PT_ERR_SHAPE;
   int st;
@@ -1075,7 +1113,7 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p) {
   if (d->split_k < 1 || (d->split_k > 1 && d->out_kind != PT_OUT_F32_ATOMIC)) return PT_ERR_ARG;
   if (d->out_kind == PT_OUT_F32_ATOMIC && (d->bias || d->row_bias || d->residual || d->residual2 || d->C2 || d->act)) return PT_ERR_ARG;
   if (d->out_kind != PT_OUT_F32_ATOMIC) {
-    const int oes = d->out_kind == PT_OUT_F32 ? 4 : es;
+    const int oes = d->out_kind == PT_OUT_F32 ? 4 : oes_t;
     if ((reinterpret_cast<uintptr_t>(d->C) & 15u) || (d->ldc * oes) % (4 * oes) != 0) return PT_ERR_ALIGN;
     if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15u)) return PT_ERR_ALIGN;
     if (d->row_bias && ((reinterpret_cast<uintptr_t>(d->row_bias) & 15u) || d->row_bias_rows <= 0 || (d->N % 4) || (d->row_bias_ld % 4))) return PT_ERR_ALIGN;
@@ -1100,6 +1138,7 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p) {
   if (p.arow_sum && (d->out_kind != PT_OUT_F32_ATOMIC || d->arow_n <= 0 || d->arow_n > d->M || (p.arow_rep > 1 && d->arow_stride < d->arow_n))) return PT_ERR_ARG;
   p.tiles_m = p.tiles_n = 0;   // set per tile configuration at launch
   p.geglu_rows = d->geglu_rows;
+  p.scale_a = p.scale_b = nullptr;
   if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
   if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
   if (d->act >= 2) {
@@ -1121,6 +1160,26 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);
   return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);
+}
+
+// fp8 operands (e4m3 weights; e4m3 or e5m2 activations / gradients), bf16 output, f32 accumulation, every epilogue of pt_gemm.
+extern "C" int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* scale_a, const float* scale_b, pt_stream stream) {
+  GemmParams p;
+  const int st = build_params(d, PT_BF16, p, 1);
+  if (st != PT_OK) return st;
+  if (a_format != PT_FP8_E4M3 && a_format != PT_FP8_E5M2) return PT_ERR_DTYPE;
+  if (!scale_a || !scale_b) return PT_ERR_ARG;
+  if (d->A.trans || d->B.trans || d->A.kind != PT_V_PLAIN || d->B.kind != PT_V_PLAIN) return PT_ERR_ARG;   // K-contiguous plain operands
+  if (d->out_kind != PT_OUT_T || d->split_k != 1 || d->K % 16 != 0) return PT_ERR_ARG;
+  p.scale_a = scale_a; p.scale_b = scale_b;
+  p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (int)((p.N + 255) / 256);
+  if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, 1);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a_format == PT_FP8_E4M3) hipLaunchKernelGGL((gemm8p_f8_kernel<1>), grid, dim3(P8_THREADS), 0, s, p);
+  else                         hipLaunchKernelGGL((gemm8p_f8_kernel<2>), grid, dim3(P8_THREADS), 0, s, p);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
 }
 
 extern "C" int64_t pt_wgrad_group_ws_floats(int target_wgs) {

@@ -106,6 +106,9 @@ class ParamStore:
         self.arena = None               # ZeroArena, created on first fused step
         self.arena_active = None        # set by the fused loss+backward path only (forward and backward are one episode)
         self.shadow_dirty = True
+        self.fp8 = False                # enable_fp8(): fp8 operands for the GEMMs fp8_pays() selects (bf16 shadows only)
+        self.shadow_version = 0         # bumped whenever the shadow is rewritten: fp8 weight copies are re-quantised lazily
+        self._w8 = {}
         with torch.no_grad():
             for p in self.params:
                 i = self.info[id(p)]
@@ -198,6 +201,29 @@ class ParamStore:
     def refresh_shadow(self):
         ops.pack_shadow(self.flat_p, self.shadow, self.seg_dev, self.n_seg)
         self.shadow_dirty = False
+        self.shadow_version += 1
+
+    def enable_fp8(self, on=True):
+        """BASELINE configs[4] ("fp8 MFMA GEMMs"): feed-forward GEMMs whose fp8 form is a net win (fp8_pays) read e4m3 weights /
+        activations and e5m2 output gradients, per-tensor current scaling; everything else stays bf16."""
+        if on and self.dtype != torch.bfloat16:
+            raise ValueError("fp8 GEMMs need the bf16 activation path (dtype=torch.bfloat16)")
+        self.fp8 = bool(on)
+
+    def w8(self, p):
+        """(W8 [N][K], W8^T [K][N], state) -- e4m3 copies of the bf16 shadow of a 2-D weight (kernel row order, i.e. GEGLU
+        rows interleaved), re-quantised on first use after every optimizer step / shadow repack."""
+        e = self._w8.get(id(p))
+        if e is None:
+            n, k = self.info[id(p)]["sshape"]
+            e = dict(w8=torch.empty(n, k, dtype=torch.uint8, device=self.device),
+                     w8t=torch.empty(k, n, dtype=torch.uint8, device=self.device),
+                     state=torch.empty(L.PT_FP8_STATE_FLOATS, dtype=torch.float32, device=self.device), version=-1)
+            self._w8[id(p)] = e
+        if e["version"] != self.shadow_version:
+            ops.fp8_quantize(self.w(p), e["w8"], e["state"], L.PT_FP8_E4M3, out_t=e["w8t"])
+            e["version"] = self.shadow_version
+        return e["w8"], e["w8t"], e["state"]
 
     def mark_dirty(self):
         """The master weights may have been written outside the fused AdamW kernel (load_state_dict, a torch optimizer
@@ -225,6 +251,7 @@ class ParamStore:
         ops.adamw_step(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.shadow, self.seg_dev, self.n_seg,
                        gnorm_sq, max_norm, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
         self.shadow_dirty = False        # the kernel rewrote the shadow of every updated tensor
+        self.shadow_version += 1
         return gnorm_sq
 
 
@@ -429,6 +456,22 @@ def _split_k(n_out, k_in, m_red, dtype):
     tiles = math.ceil(n_out / 128) * math.ceil(k_in / 128)
     nkt = math.ceil(m_red / (64 if dtype == torch.bfloat16 else 32))
     return max(1, min(SPLITK_TARGET_WGS // max(tiles, 1), nkt // 4, 64))
+
+
+def fp8_pays(M, N, K):
+    """fp8 operands are a net win when the GEMM is large enough for the 256 x 256 fp8 kernel to run near 2x the bf16 rate AND
+    the stand-alone quantisation of its M x K activation operand (two passes over M K bf16) is small beside it: wide outputs
+    over a short reduction (measured at M = 8192, tools/fp8_probe.py: N = 8192, K = 1024 saves 48 us for 13 us of quantisation;
+    N = 1024, K = 4096 saves 20 us for 45 us)."""
+    return M >= 2048 and M % 256 == 0 and N >= 4 * K // 2 and N % 256 == 0 and K % 128 == 0
+
+
+def fp8_quantize_act(x, fmt):
+    """bf16 [M][K] -> (fp8 bytes, state) with current per-tensor scaling (state[1] = scale, device-resident)."""
+    x8 = torch.empty(x.shape[0], x.shape[1], dtype=torch.uint8, device=x.device)
+    state = torch.empty(L.PT_FP8_STATE_FLOATS, dtype=torch.float32, device=x.device)
+    ops.fp8_quantize(x, x8, state, fmt)
+    return x8, state
 
 
 def linear_fwd(x, w, bias=None, residual=None, residual2=None, out=None, out_f32=False):

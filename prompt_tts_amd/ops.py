@@ -83,6 +83,28 @@ def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bi
     check(lib.pt_gemm(C.byref(d), dtype, _stream()), "pt_gemm")
 
 
+def fp8_quantize(x, out, state, fmt=L.PT_FP8_E4M3, out_t=None):
+    """bf16 [rows][cols] -> fp8 bytes (uint8 tensor) with the per-tensor scale left in state[1] (state[0] = amax)."""
+    _dev(x, out, state)
+    rows, cols = x.shape
+    check(lib.pt_fp8_quantize(_p(x), rows, cols, x.stride(0), _p(out), out.stride(0), _p(out_t), out_t.stride(0) if out_t is not None else 0,
+                              _p(state), fmt, _stream()), "pt_fp8_quantize")
+
+
+def gemm_fp8(M, N, K, a8, b8, out, state_a, state_b, a_format=L.PT_FP8_E4M3, ldc=None, bias=None, residual=None, ldr=0,
+             residual2=None, ldr2=0, alpha=1.0, act=0, out2=None, ldc2=0, act2=0):
+    """out (bf16) = scale_a scale_b a8 [M][K] b8[N][K]^T + epilogue; a8 / b8 uint8 tensors of fp8 bytes, state_* from fp8_quantize."""
+    d = L.pt_gemm_desc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.B = plain(a8), plain(b8)
+    d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
+    d.out_kind = L.PT_OUT_T; d.split_k = 1
+    d.bias = _p(bias); d.residual = _p(residual); d.ldr = ldr; d.residual2 = _p(residual2); d.ldr2 = ldr2
+    d.alpha = alpha
+    d.act = act; d.act2 = act2; d.C2 = _p(out2); d.ldc2 = ldc2
+    check(lib.pt_gemm_fp8(C.byref(d), a_format, C.c_void_p(state_a.data_ptr() + 4), C.c_void_p(state_b.data_ptr() + 4), _stream()), "pt_gemm_fp8")
+
+
 def gemm_desc(M, N, K, A, B, out, ldc=None, out_kind=L.PT_OUT_T, split_k=1, alpha=1.0, arow_sum=None, arow_n=0, arow_rep=1,
               arow_stride=0, geglu_rows=0):
     """A bare pt_gemm_desc (weight-gradient form) for wgrad_group()."""
@@ -325,6 +347,9 @@ def profile_one_step(step_fn, capture=None):
             kind = ("N", "T")[d.A.trans] + ("N", "T")[d.B.trans]
             conv = "conv" if L.PT_V_CONV in (d.A.kind, d.B.kind) else "plain"
             return f"gemm<{dt},{kind},{'atomic' if d.out_kind == L.PT_OUT_F32_ATOMIC else 'store'}>/{conv}", gemm_flops(d)
+        if name == "pt_gemm_fp8":
+            d = args[0]._obj
+            return f"gemm_fp8<{('e4m3', 'e5m2')[args[1]]} x e4m3>", gemm_flops(d)
         if name == "pt_wgrad_group":
             arr, n = args[0], args[1]
             conv = "conv" if any(arr[i].B.kind == L.PT_V_CONV for i in range(n)) else "plain"

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from ... import engine as E
+from ... import _lib as L
 from ... import ops
 
 
@@ -139,8 +140,13 @@ class FeedForward(nn.Module):
         if self._fused(st, M):
             # one launch: proj (interleaved columns, kept for the backward) and act = value * gelu(gate) from the same tile
             proj = torch.empty(M, F2, dtype=x.dtype, device=x.device)
-            ops.gemm(M, F2, x.shape[1], ops.plain(x), ops.plain(st.w(p1.weight)), proj, ops.pt_dtype(x), bias=st.f(p1.bias),
-                     act=2, out2=act, ldc2=F2 // 2)
+            if st.fp8 and E.fp8_pays(M, F2, x.shape[1]):
+                w8, _, sw = st.w8(p1.weight)
+                x8, sx = E.fp8_quantize_act(x, L.PT_FP8_E4M3)
+                ops.gemm_fp8(M, F2, x.shape[1], x8, w8, proj, sx, sw, bias=st.f(p1.bias), act=2, out2=act, ldc2=F2 // 2)
+            else:
+                ops.gemm(M, F2, x.shape[1], ops.plain(x), ops.plain(st.w(p1.weight)), proj, ops.pt_dtype(x), bias=st.f(p1.bias),
+                         act=2, out2=act, ldc2=F2 // 2)
         elif id(p1.weight) in st.geglu_ids:
             # interleaved weight, but a row count the fused epilogue does not take: stand-alone GEGLU over interleaved columns
             proj = E.linear_fwd(x, st.w(p1.weight))
@@ -163,8 +169,14 @@ class FeedForward(nn.Module):
             # ff2: weight gradient as usual; its dgrad GEMM turns d(act) into d(proj) in the epilogue (d(act) never reaches HBM)
             E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias), need_dx=False)
             dproj = torch.empty_like(proj)
-            ops.gemm(M, F2 // 2, dout.shape[1], ops.plain(dout), ops.plain(st.w(p2.weight), trans=True), dproj, ops.pt_dtype(x),
-                     ldc=F2, act=3, residual=proj, ldr=F2)
+            if st.fp8 and E.fp8_pays(M, F2 // 2, dout.shape[1]):
+                _, w8t, sw = st.w8(p2.weight)                      # W2^T [F][d]: the reduction (d) contiguous
+                d8, sd = E.fp8_quantize_act(dout, L.PT_FP8_E5M2)
+                ops.gemm_fp8(M, F2 // 2, dout.shape[1], d8, w8t, dproj, sd, sw, a_format=L.PT_FP8_E5M2, ldc=F2, act=3,
+                             residual=proj, ldr=F2)
+            else:
+                ops.gemm(M, F2 // 2, dout.shape[1], ops.plain(dout), ops.plain(st.w(p2.weight), trans=True), dproj, ops.pt_dtype(x),
+                         ldc=F2, act=3, residual=proj, ldr=F2)
             return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2)
         il = id(p1.weight) in st.geglu_ids
         dact = E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias))

@@ -113,10 +113,14 @@ class _DenoiserFn(torch.autograd.Function):
 
 
 class TTSSingleSpeaker(nn.Module):
-    def __init__(self, config, dtype=torch.bfloat16, mask_mode="ignored"):
+    def __init__(self, config, dtype=torch.bfloat16, mask_mode="ignored", fp8=False):
+        """fp8=True (bf16 only; BASELINE configs[4]): the feed-forward GEMMs that gain from it run with fp8 operands."""
         super().__init__()
         self.config = dict(config)
         self.compute_dtype = dtype
+        if fp8 and dtype != torch.bfloat16:
+            raise ValueError("fp8 GEMMs need dtype=torch.bfloat16")
+        self.fp8 = bool(fp8)
         self.text_encoder = TextEncoder(
             vocab_len=config["cmu_vocab_len"], seq_len=config["cmu_seq_len"], dim=config["cross_attention_dim"],
             attention_head_dim=config["attention_head_dim"], dropout=config["text_encoder_dropout"],
@@ -147,6 +151,7 @@ class TTSSingleSpeaker(nn.Module):
                                "(there is no CPU fallback)")
         if self._store is None or self._store.device != p0.device:
             self._store = E.ParamStore(self, p0.device, self.compute_dtype)
+            self._store.enable_fp8(self.fp8)
             self._anchor = torch.zeros(1, device=p0.device, requires_grad=True)
         return self._store
 
