@@ -240,6 +240,32 @@ def test_wgrad_group_resnet_convs(dev):
         ops.wgrad_group(mixed, _ws(dev))
 
 
+@pytest.mark.parametrize("B,n,cin,cout", [(32, 1024, 512, 512), (6, 320, 1024, 512), (2, 192, 256, 384), (1, 512, 512, 512)])
+def test_conv_wgrad_flat_item_with_boundary_corrections(dev, B, n, cin, cout, monkeypatch):
+    """engine.conv3_bwd's stride-1 weight gradient walks ONE flat item of B n rows (constant address step) and subtracts the
+    two cross-item products per conv that the zero padding excludes (rank B-1 problems in the plain group): against the
+    autograd gradient of the explicit-copies conv, and against the per-item row map (PT_CONV_WGRAD_FLAT=0)."""
+    ops, L = _ops()
+    from prompt_tts_amd import engine as E
+    dtype = torch.bfloat16
+    g = _gen(dev, 21 + B)
+    x, xf = rnd((B * n, cin), dtype, dev, g); dy, dyf = rnd((B * n, cout), dtype, dev, g)
+    w3 = torch.zeros(cout, 3 * cin, dtype=dtype, device=dev)
+    wz = torch.zeros(cout, 3, cin, device=dev, requires_grad=True)
+    _conv_ref(xf, wz, B, n, "s1").backward(dyf)
+    got = {}
+    for flat in (True, False):
+        monkeypatch.setattr(E, "CONV_WGRAD_FLAT", flat)
+        gw = torch.zeros(cout, 3 * cin, dtype=torch.float32, device=dev); gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+        E.conv3_bwd(dy, x, w3, gw, gb, B, n, n, need_dx=False)
+        E.flush_wgrads(); E.join_side_stream(dev); torch.cuda.synchronize()
+        assert relerr(gw.view(cout, 3, cin), wz.grad) < TOL[dtype]
+        assert relerr(gb, dyf.sum(0)) < TOL[dtype]
+        got[flat] = gw
+    # both forms sum the same products (other orders): far inside the bf16 tolerance of either against the reference
+    assert relerr(got[True], got[False]) < 1e-4
+
+
 # ---- GEGLU fused into the ff1 GEMM epilogue (act 2) and into the ff2 dgrad epilogue (act 3) ----------------------------------
 def _interleave_rows(w, F):
     """[2F][...] value rows | gate rows -> the interleaved order of pt_gemm act 2 (row 64q+t: t<32 value 32q+t, else gate)."""
