@@ -32,7 +32,7 @@ enum pt_fp8_format { PT_FP8_E4M3 = 0, PT_FP8_E5M2 = 1 };   /* OCP fp8: e4m3 "fn"
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc, 9 pt_transpose_seg */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -170,6 +170,16 @@ typedef struct pt_fold_seg {
 /* dst[dst_off + i] += sum_r arena[rep_off + r * rep_stride + i] for every segment (max_n = largest n). */
 int pt_fold_replicas(const float* arena, float* dst, const pt_fold_seg* segs_dev, int64_t n_segs, int n_rep,
                      int64_t max_n, pt_stream stream);
+
+/* dst[c][r] = src[r][c] for every segment, one launch (bf16; rows, cols multiples of 64; 16-byte aligned pointers and row
+ * pitches).  tile_begin = number of 64 x 64 tiles of the segments before this one; n_tiles = the total.  Keeps transposed
+ * copies of the weight shadows fresh once per optimizer step: the autograd data gradient of nn.Linear (dx = dy W) then reads
+ * W^T with the reduction index contiguous. */
+typedef struct pt_transpose_seg {
+  const void* src; void* dst;
+  int64_t rows, cols, src_ld, dst_ld, tile_begin;
+} pt_transpose_seg;
+int pt_transpose_batch(const pt_transpose_seg* segs_dev, int64_t n_seg, int64_t n_tiles, int dtype, pt_stream stream);
 
 /* dx = LN'(dy) [+ dres];  dgamma/dbeta += (f32 atomics). */
 int pt_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,

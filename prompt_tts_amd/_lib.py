@@ -72,6 +72,11 @@ class pt_encodec_stage_desc(C.Structure):
                 ("wf", C.c_void_p), ("bf", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64)]
 
 
+class pt_transpose_seg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("src_ld", C.c_int64),
+                ("dst_ld", C.c_int64), ("tile_begin", C.c_int64)]
+
+
 class pt_param_seg(C.Structure):
     _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("shadow_offset", C.c_int64),
                 ("layout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("frozen", C.c_int32)]
@@ -94,6 +99,7 @@ SIGNATURES = {
     "pt_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pt_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "pt_fold_replicas": [_vp, _vp, _vp, _i64, _i32, _i64, _vp],
+    "pt_transpose_batch": [_vp, _i64, _i64, _i32, _vp],
     "pt_groupnorm_stats": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp],
     "pt_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp],
     "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _i32, _vp],
@@ -144,7 +150,7 @@ def _load():
     lib.pt_struct_size.argtypes = [C.c_int]
     lib.pt_wgrad_group_ws_floats.restype = C.c_int64
     lib.pt_wgrad_group_ws_floats.argtypes = [C.c_int]
-    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc, pt_encodec_stage_desc)):
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc, pt_encodec_stage_desc, pt_transpose_seg)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():

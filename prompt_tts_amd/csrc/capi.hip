@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 17; }
+extern "C" int pt_abi_version(void) { return 18; }
 
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
@@ -26,6 +26,7 @@ extern "C" int pt_struct_size(int which) {
     case 6: return (int)sizeof(pt_fold_seg);
     case 7: return (int)sizeof(pt_encodec_tail_desc);
     case 8: return (int)sizeof(pt_encodec_stage_desc);
+    case 9: return (int)sizeof(pt_transpose_seg);
     default: return -1;
   }
 }

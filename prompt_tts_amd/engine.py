@@ -25,6 +25,20 @@ def _round_up(x, a):
     return (x + a - 1) // a * a
 
 
+_STORES = __import__("weakref").WeakSet()
+DGRAD_PRETRANSPOSED = __import__("os").environ.get("PT_DGRAD_PRETRANSPOSED", "1") != "0"
+
+
+def transposed_weight(w):
+    """The W^T copy some ParamStore keeps for the shadow view `w`, or None."""
+    for st in _STORES:
+        if st.device == w.device:
+            t = st.wt(w)
+            if t is not None:
+                return t
+    return None
+
+
 class ParamStore:
     """Flat storage for every parameter of `module` on `device`; `dtype` is the activation/shadow dtype."""
 
@@ -109,6 +123,8 @@ class ParamStore:
         self.fp8 = False                # enable_fp8(): fp8 operands for the GEMMs fp8_pays() selects (bf16 shadows only)
         self.shadow_version = 0         # bumped whenever the shadow is rewritten: fp8 weight copies are re-quantised lazily
         self._w8 = {}
+        self._wt, self._wt_table, self._wt_version = {}, None, -1     # transposed shadow copies for the data-gradient GEMMs
+        _STORES.add(self)
         with torch.no_grad():
             for p in self.params:
                 i = self.info[id(p)]
@@ -202,6 +218,43 @@ class ParamStore:
         ops.pack_shadow(self.flat_p, self.shadow, self.seg_dev, self.n_seg)
         self.shadow_dirty = False
         self.shadow_version += 1
+
+    # -- transposed weight copies (bf16): dx = dy W reads W^T [K][N] as a plain K-contiguous operand ------------------
+    def wt(self, w):
+        """W^T for a 2-D view `w` of the bf16 shadow (single weights, fused q|k|v stacks, the packed K/V matrix), kept fresh by
+        ONE batched transposition per shadow version; None when `w` is not such a view (f32 parity mode, odd shapes)."""
+        if not DGRAD_PRETRANSPOSED or self.dtype != torch.bfloat16 or w.dim() != 2 or not w.is_contiguous():
+            return None
+        rows, cols = w.shape
+        base = self.shadow.data_ptr()
+        if rows % 64 or cols % 64 or not (base <= w.data_ptr() < base + 2 * self.n_shadow):
+            return None
+        key = (w.data_ptr(), rows, cols)
+        e = self._wt.get(key)
+        if e is None:
+            e = self._wt[key] = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.device)
+            self._wt_table = None
+            if self._wt_version == self.shadow_version:          # the others are current: bring only the new one up to date
+                self._transpose([(key, e)])
+                return e
+        if self._wt_version != self.shadow_version:
+            if self._wt_table is None:
+                self._wt_table = self._transpose_table(list(self._wt.items()))
+            ops.transpose_batch(*self._wt_table)
+            self._wt_version = self.shadow_version
+        return e
+
+    def _transpose_table(self, items):
+        arr = (L.pt_transpose_seg * len(items))()
+        tiles = 0
+        for i, ((ptr, rows, cols), dst) in enumerate(items):
+            arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = ptr, dst.data_ptr(), rows, cols
+            arr[i].src_ld, arr[i].dst_ld, arr[i].tile_begin = cols, rows, tiles
+            tiles += (rows // 64) * (cols // 64)
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(items), tiles
+
+    def _transpose(self, items):
+        ops.transpose_batch(*self._transpose_table(items))
 
     def enable_fp8(self, on=True):
         """BASELINE configs[4] ("fp8 MFMA GEMMs"): feed-forward GEMMs whose fp8 form is a net win (fp8_pays) read e4m3 weights /
@@ -532,7 +585,8 @@ def linear_bwd(dy, x, w, gw, gbias=None, need_dx=True, dx_out=None, dx_accum=Non
         return dxt.t().contiguous()
     dx = dx_out if dx_out is not None else (dx_accum if dx_accum is not None else _empty(M, K, x))
     res2 = dx_accum
-    ops.gemm(M, K, N, ops.plain(dy), ops.plain(w, trans=True), dx, pt, ldc=dx.stride(0),
+    wt = transposed_weight(w)
+    ops.gemm(M, K, N, ops.plain(dy), ops.plain(wt) if wt is not None else ops.plain(w, trans=True), dx, pt, ldc=dx.stride(0),
              residual=dx_residual, ldr=dx_residual.stride(0) if dx_residual is not None else 0,
              residual2=res2, ldr2=res2.stride(0) if res2 is not None else 0)
     return dx

@@ -249,6 +249,10 @@ def fold_replicas(arena, dst, segs_dev, n_segs, n_rep, max_n):
     check(lib.pt_fold_replicas(_p(arena), _p(dst), _p(segs_dev), n_segs, n_rep, max_n, _stream()), "pt_fold_replicas")
 
 
+def transpose_batch(table_dev, n_seg, n_tiles):
+    check(lib.pt_transpose_batch(_p(table_dev), n_seg, n_tiles, L.PT_BF16, _stream()), "pt_transpose_batch")
+
+
 def embedding_fwd(ids, W, pos, out, S):
     BS, d = out.shape
     check(lib.pt_embedding_fwd(_p(ids), _p(W), _p(pos), _p(out), BS, S, d, W.shape[0], pt_dtype(out), _stream()),

@@ -175,8 +175,9 @@ class FeedForward(nn.Module):
                 ops.gemm_fp8(M, F2 // 2, dout.shape[1], d8, w8t, dproj, sd, sw, a_format=L.PT_FP8_E5M2, ldc=F2, act=3,
                              residual=proj, ldr=F2)
             else:
-                ops.gemm(M, F2 // 2, dout.shape[1], ops.plain(dout), ops.plain(st.w(p2.weight), trans=True), dproj, ops.pt_dtype(x),
-                         ldc=F2, act=3, residual=proj, ldr=F2)
+                w2t = st.wt(st.w(p2.weight))                       # W2^T [F][d] (plain operand) when the store keeps one
+                ops.gemm(M, F2 // 2, dout.shape[1], ops.plain(dout), ops.plain(w2t) if w2t is not None else ops.plain(st.w(p2.weight), trans=True),
+                         dproj, ops.pt_dtype(x), ldc=F2, act=3, residual=proj, ldr=F2)
             return E.linear_bwd(dproj, x, st.w(p1.weight), st.g(p1.weight), st.g(p1.bias), geglu_rows=F2 // 2)
         il = id(p1.weight) in st.geglu_ids
         dact = E.linear_bwd(dout, act, st.w(p2.weight), st.g(p2.weight), st.g(p2.bias))

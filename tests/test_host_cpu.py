@@ -138,7 +138,7 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.pt_attn_fwd(None, 1, None) == -5
     assert _lib.lib.pt_wgrad_group(None, 1, None, 0, 0, None) == -5 and _lib.lib.pt_wgrad_group_ws_floats(0) == 256 * 65536
     for i, st in enumerate((_lib.pt_operand, _lib.pt_gemm_desc, _lib.pt_attn_desc, _lib.pt_param_seg, _lib.pt_rowconv_desc,
-                            _lib.pt_lstm2_desc, _lib.pt_fold_seg, _lib.pt_encodec_tail_desc, _lib.pt_encodec_stage_desc)):
+                            _lib.pt_lstm2_desc, _lib.pt_fold_seg, _lib.pt_encodec_tail_desc, _lib.pt_encodec_stage_desc, _lib.pt_transpose_seg)):
         assert _lib.lib.pt_struct_size(i) == ctypes.sizeof(st)          # the ctypes mirror matches the C layout
 
 

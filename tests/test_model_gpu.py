@@ -141,6 +141,35 @@ def test_fused_train_steps_vs_oracle(dev, dtype, tol):
     for k in ref.state_dict():
         if "proj_out" in k:
             assert torch.equal(got[k], p0[k])          # unused parameters are never touched
+    if dtype == torch.bfloat16:
+        # the transposed weight copies the data-gradient GEMMs read follow every optimizer step: after the second AdamW each
+        # registered copy is stale until its next use, which must bring it back to exactly shadow^T
+        st = m.store
+        assert len(st._wt) >= 8 and st._wt_version != st.shadow_version
+        base = st.shadow.data_ptr()
+        for (ptr, rows, cols), _ in list(st._wt.items()):
+            view = st.shadow[(ptr - base) // 2:(ptr - base) // 2 + rows * cols].view(rows, cols)
+            assert torch.equal(st.wt(view), view.t().contiguous())
+
+
+def test_transpose_batch_many_segments(dev):
+    """pt_transpose_batch: every segment of one launch equals torch's transpose (strided source rows included)."""
+    from prompt_tts_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 64), (512, 1536), (4096, 512), (192, 320)]
+    big = torch.randn(704, 2048, generator=g).to(torch.bfloat16).to(dev)          # a strided view: src_ld > cols
+    srcs = [torch.randn(r, c, generator=g).to(torch.bfloat16).to(dev) for r, c in shapes] + [big[:640, 128:128 + 1024]]
+    dsts = [torch.empty(t.shape[1], t.shape[0], dtype=torch.bfloat16, device=dev) for t in srcs]
+    arr = (L.pt_transpose_seg * len(srcs))()
+    tiles = 0
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1]
+        arr[i].src_ld, arr[i].dst_ld, arr[i].tile_begin = a.stride(0), b.stride(0), tiles
+        tiles += (a.shape[0] // 64) * (a.shape[1] // 64)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    ops.transpose_batch(table, len(srcs), tiles)
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b, a.t().contiguous())
 
 
 def test_grad_accumulation_and_zero_grad(dev):
