@@ -104,7 +104,7 @@ def cpu_baseline(cfg, wl, S, budget_s=20.0):
     Bc = 1
     x0, noise, t, ids, mask = synthetic_batch(Bc, wl["n_q"], wl["T"], S, 4321)
     t0 = time.time(); ots.train_step(ref, opt, x0, noise, t, ids, mask); warm = time.time() - t0
-    steps = max(1, min(3, int(budget_s / max(warm, 1e-3)) - 1))
+    steps = max(1, min(12, int(budget_s / max(warm, 1e-3)) - 1))
     t0 = time.time()
     for _ in range(steps):
         ots.train_step(ref, opt, x0, noise, t, ids, mask)
@@ -114,26 +114,36 @@ def cpu_baseline(cfg, wl, S, budget_s=20.0):
 
 
 def decode_stack_bytes_per_frame(es=2):
-    """Algorithmic HBM bytes of the decode path per code frame (75 frames = one audio second): every layer's input read once
-    and output written once in the activation dtype (es bytes), weights not counted (29.7 MB, read once per batch).
-    RVQ gather 8 codes (int64) -> 128; conv k7 128 -> 512; LSTM input projection 512 -> 2048; LSTM reads 2048 + 512, writes 512;
-    stage (r, cin -> cout): transposed conv cin -> r*cout (twice where the ELU copy is a second output), residual conv3
-    r*cout -> r*cout/2, fused 1x1 + shortcut reads r*cout/2 + r*cout, writes r*cout; final conv k7 32 -> 1 sample (f32 out)."""
+    """Algorithmic HBM bytes of the decode path per code frame (75 frames = one audio second): what the launches of the bf16
+    decoder MUST move -- every launch's input read once and output written once in the activation dtype (es bytes), weights
+    not counted (29.7 MB, read once per batch).  Launch boundaries (prompt_tts_amd/encodec.py): RVQ gather; conv k7 128 -> 512;
+    LSTM input projection 512 -> 2048; [LSTM: reads 2048 + 512, writes 512 -- latency-bound, reported apart]; stage 0 (r 8,
+    512 -> 256) as three GEMMs (transposed conv writing a raw + an ELU copy, conv k3, 1x1 + shortcut); stage 1 (r 5) as the
+    transposed-conv GEMM + ONE fused residual-block launch; stage 2 (r 4) ONE fused launch; the 24 kHz tail (r 2 + final conv k7)
+    ONE fused launch.  Also returned: the same path counted layer by layer (every layer a launch, round 1's structure)."""
     b = 8 * 8 + 128 * es                       # codes in, code embedding out
     b += (128 + 512) * es                      # conv0
     b += (512 + 2048) * es                     # LSTM input projection
     lstm = (2048 + 512 + 512) * es
+    b += 512 * es + 2 * 8 * 256 * es           # stage 0 transposed conv: x1 raw + ELU copy
+    b += 8 * 256 * es + 8 * 128 * es           #   conv k3
+    b += (8 * 128 + 8 * 256) * es + 8 * 256 * es   # 1x1 + shortcut
+    b += 8 * 256 * es + 40 * 128 * es          # stage 1 transposed conv
+    b += 40 * 128 * es + 40 * 128 * es         #   fused residual block
+    b += 40 * 128 * es + 160 * 64 * es         # stage 2, one launch
+    b += 160 * 64 * es + 320 * 4               # tail, one launch: 320 f32 samples out
+    layerwise = 8 * 8 + 128 * es + (128 + 512) * es + (512 + 2048) * es
     rows, c = 1, 512
     for r in (8, 5, 4, 2):
         cout = c // 2
         rows_out = rows * r
-        copies = 1 if r * cout <= 64 else 2    # large stages keep a raw + an ELU copy of the upsampled tensor
-        b += rows * c * es + copies * rows_out * cout * es
-        b += rows_out * (cout + cout // 2) * es
-        b += rows_out * (cout // 2 + cout + cout) * es
+        copies = 1 if r * cout <= 64 else 2
+        layerwise += rows * c * es + copies * rows_out * cout * es
+        layerwise += rows_out * (cout + cout // 2) * es
+        layerwise += rows_out * (cout // 2 + cout + cout) * es
         rows, c = rows_out, cout
-    b += rows * 32 * es + rows * 4             # final conv: 32 channels in, one f32 sample out
-    return b, lstm
+    layerwise += rows * 32 * es + rows * 4
+    return b, lstm, layerwise
 
 
 def decode_cpu_baseline(budget_s=15.0):
@@ -142,10 +152,10 @@ def decode_cpu_baseline(budget_s=15.0):
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     W = oe.random_weights(0)
-    Bc, Tc = 2, 256
+    Bc, Tc = 4, 1024
     codes = torch.randint(0, 1024, (Bc, 8, Tc), generator=torch.Generator().manual_seed(7))
     t0 = time.time(); oe.decode(codes, W); warm = time.time() - t0
-    reps = max(1, min(4, int(budget_s / max(warm, 1e-3)) - 1))
+    reps = max(1, min(12, int(budget_s / max(warm, 1e-3)) - 1))
     t0 = time.time()
     for _ in range(reps):
         oe.decode(codes, W)
@@ -175,12 +185,16 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
     per = _ops.profile_one_step(lambda: dec.decode(codes))
     lstm_ms = per.get("pt_lstm2_forward", {}).get("ms_total", 0.0)
     stack_ms = sum(v["ms_total"] for k, v in per.items() if k != "pt_lstm2_forward")
-    stack_b, lstm_b = decode_stack_bytes_per_frame(2 if dtype == torch.bfloat16 else 4)
+    stack_b, lstm_b, layerwise_b = decode_stack_bytes_per_frame(2 if dtype == torch.bfloat16 else 4)
     stack_bytes = stack_b * prompts * T
     hbm = {"bound": "hbm", "kernel": "Encodec decoder conv stack (pt_gemm / pt_rowconv / pt_rvq_decode launches of one batch)",
            "achieved": stack_bytes / (stack_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
            "frac": stack_bytes / (stack_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_frame": stack_b, "ms": stack_ms,
-           "traffic": None, "note": "algorithmic bytes = each layer's input read once + output written once (bf16), weights excluded"}
+           "traffic": None, "layer_by_layer_bytes_per_frame": layerwise_b,
+           "mfma_tflops_of_the_stack": 2 * (19863552 - 4 * 512 * (512 + 1024)) * prompts * T / (stack_ms * 1e-3) / 1e12,
+           "note": "algorithmic bytes = every LAUNCH's input read once + output written once (bf16), weights excluded; the fused "
+                   "stages keep their intermediates in LDS, so the stack moves a third of the layer-by-layer bytes and is "
+                   "bound by the fused kernels' MFMA / LDS work rather than by HBM"}
     # token stage of configs[3] (build-defined ops, SURVEY 8a'): RVQ-codebook logits head Linear(d -> n_q * 1024) on (B, T, d)
     # hidden states, then greedy / top-k = 32 sampling per (prompt, codebook, frame) with injected uniforms
     from prompt_tts_amd import engine as E, ops
