@@ -289,3 +289,29 @@ def test_async_checkpoint_writer_and_adamw_state_dict_format(tmp_path):
     w.save(str(tmp_path / "no_such_dir" / "x.pt"), {"a": 1})
     with pytest.raises(Exception):
         w.wait()
+
+
+def test_wgrad_queue_deferred_problems_never_share_a_launch_with_their_partner(monkeypatch):
+    """engine._WgradQueue: a deferred problem (the boundary corrections of a flat conv weight gradient accumulate into the same
+    destination as their conv; one launch's fold adds partials with plain read-modify-writes) joins the NEXT group of its class,
+    and the final flush drains everything."""
+    import torch
+    from prompt_tts_amd import engine as E
+    launches = []
+    monkeypatch.setattr(E.ops, "wgrad_group", lambda descs, ws, wgs: launches.append(list(descs)))
+    monkeypatch.setattr(E, "on_side_stream", lambda fn, *tensors: fn())
+    monkeypatch.setattr(E.ops, "wgrad_group_ws_floats", lambda wgs: 16)
+    q = E._WgradQueue(torch.device("cpu"))
+    for conv in range(7):                                 # 7 convs: main problem + two deferred corrections each
+        q.add(1, f"main{conv}", 12, ())
+        q.add(1, f"c{conv}a", 4, (), defer=True)
+        q.add(1, f"c{conv}b", 4, (), defer=True)
+    q.add(0, "plain", 8, ())
+    q.flush()
+    flat = [d for grp in launches for d in grp]
+    assert sorted(flat) == sorted([f"main{i}" for i in range(7)] + [f"c{i}{s}" for i in range(7) for s in "ab"] + ["plain"])
+    assert all(len(grp) <= E.ops.WGRAD_GROUP_MAX for grp in launches)
+    where = {d: gi for gi, grp in enumerate(launches) for d in grp}
+    for i in range(7):
+        assert where[f"c{i}a"] > where[f"main{i}"] and where[f"c{i}b"] > where[f"main{i}"]     # strictly later launches
+    assert not q.lists[0] and not q.lists[1] and not q.deferred[0] and not q.deferred[1]
