@@ -32,6 +32,7 @@ enum pt_fp8_format { PT_FP8_E4M3 = 0, PT_FP8_E5M2 = 1 };   /* OCP fp8: e4m3 "fn"
 
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
+const char* pt_last_hip_error(void);            /* hipGetErrorString of the HIP error behind the most recent PT_ERR_LAUNCH */
 int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc, 9 pt_transpose_seg */
 
 /* ------------------------------------------------------------------------------------------------

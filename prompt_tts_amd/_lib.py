@@ -6,6 +6,11 @@ import fails loudly.  Nothing here touches ``oracle/``.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7, and the
+#               library here resolves the same soname.  Loaded after torch it shares torch's HIP runtime (streams and device
+#               pointers are then the same objects); loaded BEFORE torch the process ends up with two HIP runtimes and every
+#               launch here fails with "no ROCm-capable device is detected".
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
 
@@ -146,6 +151,7 @@ def _load():
     lib.pt_abi_version.restype = C.c_int
     lib.pt_status_string.restype = C.c_char_p
     lib.pt_status_string.argtypes = [C.c_int]
+    lib.pt_last_hip_error.restype = C.c_char_p
     lib.pt_struct_size.restype = C.c_int
     lib.pt_struct_size.argtypes = [C.c_int]
     lib.pt_wgrad_group_ws_floats.restype = C.c_int64
@@ -165,4 +171,5 @@ lib = _load()
 
 def check(status, what):
     if status != 0:
-        raise RuntimeError(f"{what}: {lib.pt_status_string(status).decode()} (status {status})")
+        hip = f" [{lib.pt_last_hip_error().decode()}]" if status == -3 else ""        # PT_ERR_LAUNCH: the HIP error behind it
+        raise RuntimeError(f"{what}: {lib.pt_status_string(status).decode()} (status {status}){hip}")

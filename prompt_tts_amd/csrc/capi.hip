@@ -3,6 +3,9 @@
 
 extern "C" int pt_abi_version(void) { return 18; }
 
+extern "C" { int pt_g_last_hip_error = 0; }
+extern "C" const char* pt_last_hip_error(void) { return hipGetErrorString((hipError_t)pt_g_last_hip_error); }
+
 extern "C" const char* pt_status_string(int status) {
   switch (status) {
     case PT_OK: return "ok";

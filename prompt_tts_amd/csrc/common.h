@@ -122,10 +122,12 @@ __device__ __forceinline__ void gelu_erf_fast(float x, float& gelu, float& dgelu
 }
 
 // host-side launch check
+extern "C" int pt_g_last_hip_error;      // capi.hip: the hipError_t behind the most recent PT_ERR_LAUNCH (diagnostics)
 #define PT_LAUNCH_CHECK()                                  \
   do {                                                     \
-    if (hipPeekAtLastError() != hipSuccess) {              \
-      (void)hipGetLastError();                             \
+    const hipError_t pt_e_ = hipGetLastError();            \
+    if (pt_e_ != hipSuccess) {                             \
+      pt_g_last_hip_error = (int)pt_e_;                    \
       return PT_ERR_LAUNCH;                                \
     }                                                      \
   } while (0)

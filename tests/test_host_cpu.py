@@ -124,7 +124,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert declared - {"pt_abi_version", "pt_status_string", "pt_struct_size", "pt_wgrad_group_ws_floats"} == set(_lib.SIGNATURES)   # binding == header
+    assert declared - {"pt_abi_version", "pt_status_string", "pt_last_hip_error", "pt_struct_size", "pt_wgrad_group_ws_floats"} == set(_lib.SIGNATURES)   # binding == header
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (pt_\w+)", out))
     assert exported >= declared
@@ -315,3 +315,19 @@ def test_wgrad_queue_deferred_problems_never_share_a_launch_with_their_partner(m
     for i in range(7):
         assert where[f"c{i}a"] > where[f"main{i}"] and where[f"c{i}b"] > where[f"main{i}"]     # strictly later launches
     assert not q.lists[0] and not q.lists[1] and not q.deferred[0] and not q.deferred[1]
+
+
+def test_importing_the_package_first_loads_one_hip_runtime():
+    """The PyTorch-ROCm wheel bundles its own libamdhip64.so.7; the C-ABI library resolves the same soname.  Imported before
+    torch it used to pull in /opt/rocm's copy as a SECOND HIP runtime (every launch then failed with "no ROCm-capable device");
+    prompt_tts_amd._lib therefore imports torch before it loads the library."""
+    import subprocess
+    import sys
+    code = ("import prompt_tts_amd, torch\n"
+            "maps = open('/proc/self/maps').read().split('\\n')\n"
+            "print(sorted({l.split()[-1] for l in maps if 'libamdhip64' in l}))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    libs = eval(out.stdout.strip().split("\n")[-1])
+    assert len(libs) == 1, libs
