@@ -399,6 +399,9 @@ def main():
                 sym = SYMBOL.get(name, name).split(" ")[0]
                 hit = [k for k in pmc["kernels"] if sym in k["kernel"]]
                 r["traffic"] = hit[0]["bytes_per_launch"] if hit else None
+                if hit:     # the K = 512 launches of this class move 67-570 MB for 17-137 GFLOP: report the HBM side as well
+                    r["hbm_gbps_from_pmc_traffic"] = hit[0]["bytes_per_launch"] / (mf[name]["ms_avg"] * 1e-3) / 1e9
+                    r["hbm_frac_of_8tbps"] = r["hbm_gbps_from_pmc_traffic"] / 8000.0
             calls, iso_us, iso_tf = ops.replay_captured(captured, name)
             r["isolated"] = {"calls": calls, "avg_us": iso_us, "achieved": iso_tf, "frac": iso_tf / peak,
                              "note": "the same launches of one step replayed back to back, alone on the chip"}
