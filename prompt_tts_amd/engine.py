@@ -39,6 +39,16 @@ def transposed_weight(w):
     return None
 
 
+def conv_dgrad_weight(w3, cout, cin_pad):
+    """The flipped + transposed copy [cin_pad][3*cout] some ParamStore keeps for the conv k3 weight shadow `w3`, or None."""
+    for st in _STORES:
+        if st.device == w3.device:
+            t = st.wd(w3, cout, cin_pad)
+            if t is not None:
+                return t
+    return None
+
+
 class ParamStore:
     """Flat storage for every parameter of `module` on `device`; `dtype` is the activation/shadow dtype."""
 
@@ -232,29 +242,56 @@ class ParamStore:
         key = (w.data_ptr(), rows, cols)
         e = self._wt.get(key)
         if e is None:
-            e = self._wt[key] = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.device)
-            self._wt_table = None
-            if self._wt_version == self.shadow_version:          # the others are current: bring only the new one up to date
-                self._transpose([(key, e)])
-                return e
+            dst = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.device)
+            e = self._wt[key] = (dst, [(w.data_ptr(), dst.data_ptr(), rows, cols, cols, rows)])
+            return self._wt_register(e)
+        self._wt_refresh()
+        return e[0]
+
+    def wd(self, w3, cout, cin_pad):
+        """Data-gradient operand of a Conv1d k=3 weight shadow `w3` [Cout][3][cin_pad]: Wd [cin_pad][3*cout] with
+        Wd[ci][t*cout + co] = W[co][2 - t][ci] (flipped taps, the reduction contiguous) -- three transposed sub-matrices."""
+        if not DGRAD_PRETRANSPOSED or self.dtype != torch.bfloat16 or w3.dim() != 2 or not w3.is_contiguous():
+            return None
+        base = self.shadow.data_ptr()
+        if cout % 64 or cin_pad % 64 or w3.shape[1] != 3 * cin_pad or cout > w3.shape[0] or \
+                not (base <= w3.data_ptr() < base + 2 * self.n_shadow):
+            return None
+        key = (w3.data_ptr(), cout, -cin_pad)
+        e = self._wt.get(key)
+        if e is None:
+            dst = torch.empty(cin_pad, 3 * cout, dtype=torch.bfloat16, device=self.device)
+            segs = [(w3.data_ptr() + 2 * (2 - t) * cin_pad, dst.data_ptr() + 2 * t * cout, cout, cin_pad, 3 * cin_pad, 3 * cout)
+                    for t in range(3)]
+            e = self._wt[key] = (dst, segs)
+            return self._wt_register(e)
+        self._wt_refresh()
+        return e[0]
+
+    def _wt_register(self, e):
+        self._wt_table = None
+        if self._wt_version == self.shadow_version:              # the others are current: bring only the new one up to date
+            ops.transpose_batch(*self._transpose_table([e]))
+        else:
+            self._wt_refresh()
+        return e[0]
+
+    def _wt_refresh(self):
         if self._wt_version != self.shadow_version:
             if self._wt_table is None:
-                self._wt_table = self._transpose_table(list(self._wt.items()))
+                self._wt_table = self._transpose_table(list(self._wt.values()))
             ops.transpose_batch(*self._wt_table)
             self._wt_version = self.shadow_version
-        return e
 
-    def _transpose_table(self, items):
-        arr = (L.pt_transpose_seg * len(items))()
+    def _transpose_table(self, entries):
+        segs = [sg for _, sgs in entries for sg in sgs]
+        arr = (L.pt_transpose_seg * len(segs))()
         tiles = 0
-        for i, ((ptr, rows, cols), dst) in enumerate(items):
-            arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = ptr, dst.data_ptr(), rows, cols
-            arr[i].src_ld, arr[i].dst_ld, arr[i].tile_begin = cols, rows, tiles
+        for i, (src, dst, rows, cols, src_ld, dst_ld) in enumerate(segs):
+            arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = src, dst, rows, cols
+            arr[i].src_ld, arr[i].dst_ld, arr[i].tile_begin = src_ld, dst_ld, tiles
             tiles += (rows // 64) * (cols // 64)
-        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(items), tiles
-
-    def _transpose(self, items):
-        ops.transpose_batch(*self._transpose_table(items))
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(segs), tiles
 
     def enable_fp8(self, on=True):
         """BASELINE configs[4] ("fp8 MFMA GEMMs"): feed-forward GEMMs whose fp8 form is a net win (fp8_pays) read e4m3 weights /
@@ -655,17 +692,19 @@ def conv3_bwd(dy, x, w3, gw, gbias, B, n_in, n_out, rowmap=L.PT_MAP_S1, cin=None
         on_side_stream(wgrad, dy, x)
     if not need_dx:
         return None
+    # the dgrad reads the flipped weights with the reduction (tap, cout) contiguous: a kept copy when the store has one
+    wd = conv_dgrad_weight(w3, cout, cin) if w3.shape[1] == 3 * cin else None
     if rowmap == L.PT_MAP_UP2:
         # dgrad of (nearest x2 -> conv): stride-1 dgrad at the upsampled length, then fold row pairs
         dxu = _empty(B * 2 * n_in, cin, x)
         ops.gemm(B * 2 * n_in, cin, 3 * cout, ops.conv(dy, cout, 2 * n_in, n_out, L.PT_MAP_S1),
-                 ops.wflip(w3, cout, cin), dxu, pt)
+                 ops.plain(wd) if wd is not None else ops.wflip(w3, cout, cin), dxu, pt)
         dx = _empty(B * n_in, cin, x)
         ops.pairsum_rows(dxu, dx)
         return dx
     dx = _empty(B * n_in, cin, x)
     ops.gemm(B * n_in, cin, 3 * cout, ops.conv(dy, cout, n_in, n_out, _ROWMAP_DGRAD[rowmap]),
-             ops.wflip(w3, cout, cin), dx, pt,
+             ops.plain(wd) if wd is not None else ops.wflip(w3, cout, cin), dx, pt,
              residual=dx_residual, ldr=dx_residual.stride(0) if dx_residual is not None else 0)
     return dx
 

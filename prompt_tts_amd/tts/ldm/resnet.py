@@ -110,7 +110,8 @@ class ResnetBlock1D(nn.Module):
                          split_k=E._split_k(Cout, Cin, M, x1.dtype))
                 ops.colsum(dout, st.g(self.conv_shortcut.bias), M, Cout)
             dres = torch.empty(M, Cin, dtype=x1.dtype, device=x1.device)
-            ops.gemm(M, Cin, Cout, ops.plain(dout), ops.plain(w, trans=True), dres, pt)
+            wt = E.transposed_weight(w)                 # W^T [Cin][Cout] when the store keeps one (bf16)
+            ops.gemm(M, Cin, Cout, ops.plain(dout), ops.plain(wt) if wt is not None else ops.plain(w, trans=True), dres, pt)
         else:
             dres = dout
         return E.groupnorm_bwd(da1, x1, x2, s1, st.f(self.norm1.weight), st.f(self.norm1.bias),

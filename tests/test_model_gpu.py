@@ -148,8 +148,15 @@ def test_fused_train_steps_vs_oracle(dev, dtype, tol):
         assert len(st._wt) >= 8 and st._wt_version != st.shadow_version
         base = st.shadow.data_ptr()
         for (ptr, rows, cols), _ in list(st._wt.items()):
-            view = st.shadow[(ptr - base) // 2:(ptr - base) // 2 + rows * cols].view(rows, cols)
-            assert torch.equal(st.wt(view), view.t().contiguous())
+            off = (ptr - base) // 2
+            if cols > 0:                                   # plain weight: W^T
+                view = st.shadow[off:off + rows * cols].view(rows, cols)
+                assert torch.equal(st.wt(view), view.t().contiguous())
+            else:                                          # conv k3 weight [Cout][3][cin_pad]: flipped taps, transposed
+                cin_pad = -cols
+                w3 = st.shadow[off:off + rows * 3 * cin_pad].view(rows, 3 * cin_pad)
+                want = w3.view(rows, 3, cin_pad).flip(1).permute(2, 1, 0).reshape(cin_pad, 3 * rows).contiguous()
+                assert torch.equal(st.wd(w3, rows, cin_pad), want)
 
 
 def test_transpose_batch_many_segments(dev):
