@@ -383,24 +383,27 @@ def main():
                 out["roofline"]["traffic"] = pmc["step_bytes"]
                 out["roofline"]["traffic_note"] = f"HBM-side bytes of one step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/{cand})"
                 break
-        SYMBOL = {   # label -> kernel symbol(s) in the rocprofv3 summaries
-            "wgrad_group<bf16>/plain": "wgrad8p_group_kernel<0>", "wgrad_group<bf16>/conv": "wgrad8p_group_kernel<1>",
-            "gemm<bf16,NN,store>/plain": "gemm8p_kernel<false, false, false, 0, 0> (>= 192 tiles of 256x256) / gemm_kernel<bf16_t, false, false, false, 0, 0, 128, 128>",
-            "gemm<bf16,NT,store>/plain": "gemm8p_kernel<false, true, false, 0, 0> (>= 192 tiles of 256x256) / gemm_kernel<bf16_t, false, true, false, 0, 0, 128, 128>",
-            "gemm<bf16,NN,store>/conv": "gemm8p_kernel<false, false, false, 1, 0> / gemm_kernel<bf16_t, false, false, false, 1, 0, 128, 128>",
-            "gemm<bf16,NT,store>/conv": "gemm8p_kernel<false, true, false, 1, 2> / gemm_kernel<bf16_t, false, true, false, 1, 2, 128, 128>"}
+        SYMBOL = {   # label -> kernel symbols of the class in the rocprofv3 summaries (which one a launch takes: csrc/gemm.hip pick_tile)
+            "wgrad_group<bf16>/plain": ["wgrad8p_group_kernel<0>"], "wgrad_group<bf16>/conv": ["wgrad8p_group_kernel<1>"],
+            "gemm<bf16,NN,store>/plain": ["gemm_kernel<bf16_t, false, false, false, 0, 0, 256, 256>",      # >= 192 tiles of 256x256, K < 1024
+                                          "gemm8p_kernel<false, false, false, 0, 0>",                       # >= 192 tiles, K >= 1024
+                                          "gemm_kernel<bf16_t, false, false, false, 0, 0, 128, 128>"],     # fewer tiles
+            "gemm<bf16,NT,store>/plain": ["gemm8p_kernel<false, true, false, 0, 0>", "gemm_kernel<bf16_t, false, true, false, 0, 0, 256, 256>",
+                                          "gemm_kernel<bf16_t, false, true, false, 0, 0, 128, 128>"],
+            "gemm<bf16,NN,store>/conv": ["gemm8p_kernel<false, false, false, 1, 0>", "gemm_kernel<bf16_t, false, false, false, 1, 0, 256, 256>",
+                                         "gemm_kernel<bf16_t, false, false, false, 1, 0, 128, 128>"],
+            "gemm<bf16,NT,store>/conv": ["gemm8p_kernel<false, true, false, 1, 2>", "gemm_kernel<bf16_t, false, true, false, 1, 2, 128, 128>"]}
 
         def kernel_roofline(name, note):
-            r = {"kernel": name, "symbol": SYMBOL.get(name, name), "bound": "mfma", "calls_per_step": mf[name]["calls"],
+            r = {"kernel": name, "symbol": " | ".join(SYMBOL.get(name, [name])), "bound": "mfma", "calls_per_step": mf[name]["calls"],
                  "avg_us": mf[name]["ms_avg"] * 1e3, "algorithmic_gflop_per_launch": mf[name]["gflop_avg"],
                  "achieved": mf[name]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": mf[name]["tflops"] / peak, "traffic": None,
                  "share_of_step": mf[name]["ms_total"] / (step_s * 1e3), "note": note}
             if pmc is not None:
-                sym = SYMBOL.get(name, name).split(" ")[0]
-                hit = [k for k in pmc["kernels"] if sym in k["kernel"]]
-                r["traffic"] = hit[0]["bytes_per_launch"] if hit else None
-                if hit:     # the K = 512 launches of this class move 67-570 MB for 17-137 GFLOP: report the HBM side as well
-                    r["hbm_gbps_from_pmc_traffic"] = hit[0]["bytes_per_launch"] / (mf[name]["ms_avg"] * 1e-3) / 1e9
+                hit = [k for k in pmc["kernels"] if any(sym in k["kernel"] for sym in SYMBOL.get(name, [name]))]
+                if hit:     # call-weighted over the class's kernels; the K = 512 launches move 67-570 MB for 17-137 GFLOP: HBM side too
+                    r["traffic"] = sum(k["bytes_per_launch"] * k["calls_per_step"] for k in hit) / sum(k["calls_per_step"] for k in hit)
+                    r["hbm_gbps_from_pmc_traffic"] = r["traffic"] / (mf[name]["ms_avg"] * 1e-3) / 1e9
                     r["hbm_frac_of_8tbps"] = r["hbm_gbps_from_pmc_traffic"] / 8000.0
             calls, iso_us, iso_tf = ops.replay_captured(captured, name)
             r["isolated"] = {"calls": calls, "avg_us": iso_us, "achieved": iso_tf, "frac": iso_tf / peak,
