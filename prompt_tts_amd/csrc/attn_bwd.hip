@@ -1,5 +1,5 @@
 // Flash attention backward for gfx950: P is recomputed from Q, K and the forward's LSE.
-//   delta kernel : delta[q] = rowsum(dO * O)                                   (HBM-bound)
+//   delta[q] = rowsum(dO * O) is formed inside the dQ kernel (which runs first) and read by the dK/dV kernel
 //   dK/dV kernel : a wave owns 32 keys (K, V as register B fragments, dK^T/dV^T accumulators in registers)
 //                  and sweeps the queries in 32-row Q/dO tiles staged in LDS   -> no cross-workgroup sums
 //   dQ kernel    : a wave owns 32 queries (Q, dO as register B fragments) and sweeps 64-key K/V tiles
@@ -8,29 +8,6 @@
 #include "attn_common.h"
 
 namespace {
-
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
-  constexpr int EPC = 16 / (int)sizeof(T), CPR = D / EPC;       // CPR lanes cooperate on one (q, head) row
-  const int64_t rows = (int64_t)p.B * p.Nq * p.H;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t row = gid / CPR; const int c = (int)(gid - row * CPR);
-  float acc = 0.f;
-  if (row < rows) {
-    const int64_t bq = row / p.H; const int h = (int)(row - bq * p.H);
-    const int64_t b = bq / p.Nq, q = bq - b * p.Nq;
-    Vec16<T> a = load16(reinterpret_cast<const T*>(p.d_o) + bq * p.lddo + h * D + c * EPC);
-    Vec16<T> o = load16(reinterpret_cast<const T*>(p.o) + bq * p.ldo + h * D + c * EPC);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) acc += a.get(e) * o.get(e);
-#pragma unroll
-    for (int off = CPR >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (c == 0) p.delta[((int64_t)b * p.H + h) * p.Nq + q] = acc;
-  } else {
-#pragma unroll
-    for (int off = CPR >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  }
-}
 
 // ---- dK, dV -----------------------------------------------------------------------------------------------
 template <typename T, int D>
@@ -202,20 +179,33 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
   const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Nk * p.ldk + h * D;
   const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Nk * p.ldv + h * D;
   const T* DO = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.Nq * p.lddo + h * D;
+  const T* O = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.Nq * p.ldo + h * D;
   const float* LSE = p.lse + ((int64_t)b * p.H + h) * p.Nq;
-  const float* DELTA = p.delta + ((int64_t)b * p.H + h) * p.Nq;
+  float* DELTA = p.delta + ((int64_t)b * p.H + h) * p.Nq;
 
+  // delta[q] = rowsum(dO * O) is formed HERE from the dO fragments this wave owns anyway (lane (li, g) holds 8 consecutive
+  // columns per 32-column step of row li: the four g lanes of a row cover all D columns) and published for the dK/dV kernel,
+  // which is launched after this one: no separate pass over dO and O.
   Frag<T> fq[2][KS], fdo[2][KS];
   float ls[2], de[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     int row = q0 + 16 * qt + li; row = row < p.Nq ? row : p.Nq - 1;
-    ls[qt] = LSE[row] * PT_LOG2E; de[qt] = DELTA[row];
+    ls[qt] = LSE[row] * PT_LOG2E;
+    float acc = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       frag_load_global(fq[qt][ks], Q + (int64_t)row * p.ldq + ks * 32 + 8 * g);
       frag_load_global(fdo[qt][ks], DO + (int64_t)row * p.lddo + ks * 32 + 8 * g);
+      Frag<T> fo;
+      frag_load_global(fo, O + (int64_t)row * p.ldo + ks * 32 + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)fdo[qt][ks].v[e] * (float)fo.v[e];
     }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    de[qt] = acc;
+    if (g == 0 && q0 + 16 * qt + li < p.Nq) DELTA[q0 + 16 * qt + li] = acc;
   }
   f32x4_t dq[DT][2];
 #pragma unroll
@@ -318,11 +308,9 @@ template <typename T, int D> int launch_bwd(const AttnParams& p, hipStream_t s) 
   int st;
   if ((st = set_lds(&attn_bwd_kv_kernel<T, D>, lds_kv, a1))) return st;
   if ((st = set_lds(&attn_bwd_q_kernel<T, D>, lds_q, a2))) return st;
-  constexpr int CPR = D / (16 / (int)sizeof(T));
-  const int64_t dthreads = (int64_t)p.B * p.Nq * p.H * CPR;
-  hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)((dthreads + 255) / 256)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3((unsigned)(((p.Nk + 127) / 128) * p.H * p.B)), dim3(256), lds_kv, s, p);
+  // dQ first: it also produces delta (rowsum(dO * O)) for the dK/dV kernel that follows on the same stream
   hipLaunchKernelGGL((attn_bwd_q_kernel<T, D>), dim3((unsigned)(((p.Nq + 127) / 128) * p.H * p.B)), dim3(256), lds_q, s, p);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3((unsigned)(((p.Nk + 127) / 128) * p.H * p.B)), dim3(256), lds_kv, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
