@@ -1039,9 +1039,9 @@ int launch_cfg(GemmParams p, hipStream_t s) {
   return PT_OK;
 }
 
-// Short reductions (K < PT_GEMM_8P_MIN_K, default 1024: the K = 512 linears) take the two-stage 256 x 256 kernel instead of the
+// Short reductions (K < PT_GEMM_8P_MIN_K, default 1536: the K = 512 linears of config B, the K = 1024 ones of config E) take the two-stage 256 x 256 kernel instead of the
 // eight-phase one: with 8 k-tiles per tile the eight-phase prologue / staggered drain is a third of the tile's life, and the
-// simpler kernel is 8 - 15 % faster alone (tools/tile_probe.py) and 1.2 ms per step in the benchmark.
+// simpler kernel is 8 - 15 % faster alone (tools/tile_probe.py), 1.2 ms per step in the benchmark and 1 % of a config E step.
 // Tile choice.  PT_GEMM_TILE=128|256|512|8 (= 128x128 | 256x128 | 256x256 two-stage | 256x256 eight-phase) forces one
 // configuration for A/B probing (tools/gemm_probe.py); PT_GEMM_8P_MASK selects which GEMM classes may use the eight-phase
 // kernel (bit 0 forward plain, 1 dgrad plain, 2 conv forward, 3 conv dgrad, 4 wgrad).
@@ -1049,7 +1049,7 @@ inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
   static int forced = -1, mask = -1, min8pk = -1;
   if (forced < 0) { const char* e = getenv("PT_GEMM_TILE"); forced = e ? atoi(e) : 0; }
   if (mask < 0) { const char* e = getenv("PT_GEMM_8P_MASK"); mask = e ? atoi(e) : 0x0f; }
-  if (min8pk < 0) { const char* e = getenv("PT_GEMM_8P_MIN_K"); min8pk = e ? atoi(e) : 1024; }
+  if (min8pk < 0) { const char* e = getenv("PT_GEMM_8P_MIN_K"); min8pk = e ? atoi(e) : 1536; }
   if (forced == 128 || forced == 256 || forced == 512 || forced == 8) return forced;
   const int64_t tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.split_k;
   if (bf16 && ((mask >> cls) & 1) && tiles256 >= 192) return p.K >= min8pk ? 8 : 512;
