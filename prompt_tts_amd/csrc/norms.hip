@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm "slab" kernels (bf16, N <= 1024 tokens per item): ONE launch per direction.  A workgroup of 64 CCH threads owns a
+// GroupNorm "slab" kernels (bf16, N <= 1024 tokens per item; N <= 2048 for the 32-channel slab): ONE launch per direction.  A workgroup of 64 CCH threads owns a
 // slab of 8 CCH channels (whole groups; CCH = 4: 32 channels, 256 threads) of one batch item and keeps it in REGISTERS (x:
 // 16 B chunks, NCH per thread; backward: x and dy), so statistics / group sums and the normalisation are one pass: each
 // activation byte is read once (the two-pass kernels read x twice forward, x and dy twice backward) and all of a thread's
@@ -596,10 +596,12 @@ inline int gn_slab_cch(int64_t N, int64_t C1, int64_t C2, int64_t G) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("PT_GN_SLAB"); enabled = e ? atoi(e) : 1; }
   const int64_t C = C1 + C2;
-  if (!enabled || G <= 0 || C % G != 0 || N < 1 || N > 1024) return 0;
+  if (!enabled || G <= 0 || C % G != 0 || N < 1 || N > 2048) return 0;
   const int64_t cpg = C / G;
+  // N <= 2048 (config E's 2048-token items): 32 chunks per thread, for the 256-thread slab only -- one wave per SIMD, so the
+  // backward's 256 registers of x / dy plus its temporaries fit the 512 (arch + acc) registers a lone wave may use
   if ((cpg == 8 || cpg == 16 || cpg == 32) && C1 % 32 == 0 && C2 % 32 == 0) return 4;
-  if (cpg == 64 && C1 % 64 == 0 && C2 % 64 == 0) return 8;
+  if (cpg == 64 && C1 % 64 == 0 && C2 % 64 == 0 && N <= 1024) return 8;
   return 0;
 }
 #define GN_SLAB_LAUNCH(KERNEL, CCH, N, B, s, p)                                                              \
@@ -609,7 +611,8 @@ inline int gn_slab_cch(int64_t N, int64_t C1, int64_t C2, int64_t G) {
     else if ((N) <= 128) hipLaunchKernelGGL((KERNEL<2, CCH>), grid, blk, 0, s, p);                           \
     else if ((N) <= 256) hipLaunchKernelGGL((KERNEL<4, CCH>), grid, blk, 0, s, p);                           \
     else if ((N) <= 512) hipLaunchKernelGGL((KERNEL<8, CCH>), grid, blk, 0, s, p);                           \
-    else hipLaunchKernelGGL((KERNEL<16, CCH>), grid, blk, 0, s, p);                                          \
+    else if ((N) <= 1024 || CCH != 4) hipLaunchKernelGGL((KERNEL<16, CCH>), grid, blk, 0, s, p);             \
+    else hipLaunchKernelGGL((KERNEL<(CCH == 4 ? 32 : 16), CCH>), grid, blk, 0, s, p);                        \
   } while (0)
 
 template <typename T> int gn_geom(GnGeom& g, int64_t N, int64_t C1, int64_t C2, int64_t G) {

@@ -300,9 +300,11 @@ def test_groupnorm(dev, dtype, B, N, C1, C2, G, silu):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,C1,C2,G,silu", [(2, 1024, 512, 0, 32, True), (2, 96, 256, 256, 32, True), (3, 700, 512, 512, 32, True),
                                                (2, 70, 64, 0, 32, False), (1, 1030, 128, 0, 8, True), (2, 200, 512, 0, 8, True),
-                                               (2, 64, 96, 32, 16, False)])
+                                               (2, 64, 96, 32, 16, False),
+                                               (2, 2048, 1024, 0, 32, True), (2, 1900, 512, 512, 32, True), (2, 2048, 1024, 1024, 32, True)])
 def test_groupnorm_fused_forward_backward(dev, dtype, B, N, C1, C2, G, silu):
-    """pt_groupnorm_fwd (one slab kernel for bf16, N <= 1024, whole 64-channel slabs) + pt_groupnorm_bwd against torch."""
+    """pt_groupnorm_fwd (one slab kernel for bf16: N <= 1024, or N <= 2048 with 32-channel slabs -- config E's items; the
+    last case, 64 channels per group at N = 2048, takes the two-pass kernels) + pt_groupnorm_bwd against torch."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(13)
     C = C1 + C2
