@@ -1090,6 +1090,9 @@ int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
     if (ka == 0) return launch<T, false, false, false, 0, 0>(p, s);
     if (ka == 1) return launch<T, false, false, false, 1, 0>(p, s);
   }
+  if constexpr (std::is_same<T, float>::value) {                 // skinny f32 forward under split-K (time-embedding projections)
+    if (!ta && !tb && atomic && ka == 0 && kb == 0) return launch_cfg<T, false, false, true, 0, 0, 128, 128>(p, s);
+  }
   if (!ta && tb && !atomic) {                                    // dgrad
     if (ka == 0 && kb == 0) return launch<T, false, true, false, 0, 0>(p, s);
     if (ka == 1 && kb == 2) return launch<T, false, true, false, 1, 2>(p, s);

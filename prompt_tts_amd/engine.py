@@ -581,6 +581,19 @@ def fp8_quantize_act(x, fmt):
 def linear_fwd(x, w, bias=None, residual=None, residual2=None, out=None, out_f32=False):
     M, K = x.shape
     N = w.shape[0]
+    if (M <= 128 and N >= 2048 and K >= 512 and x.dtype == torch.float32 and out is None and residual is None
+            and residual2 is None and _arena[0] is not None):      # fused training episode only: inference stays run-to-run bitwise
+        # skinny f32 forward (the batched time-embedding projection: 32 rows against a [sum Cout][4 C0] weight, 130 MB): as one
+        # 128-row tile per 128 columns it is 124 workgroups walking the whole reduction serially at 0.4 TB/s; split-K over
+        # the reduction puts ~1000 workgroups on the weight stream (f32 atomics into the bias-initialised output)
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)      # never a view of the bias (expand(1, N) is contiguous)
+        if bias is not None:
+            out.copy_(bias.to(torch.float32).expand(M, N))
+        else:
+            out.zero_()
+        ops.gemm(M, N, K, ops.plain(x), ops.plain(w), out, ops.pt_dtype(x), ldc=N, out_kind=L.PT_OUT_F32_ATOMIC,
+                 split_k=max(1, min(8, K // 32 // 4)))
+        return out
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     ops.gemm(M, N, K, ops.plain(x), ops.plain(w), out, ops.pt_dtype(x), ldc=out.stride(0),
