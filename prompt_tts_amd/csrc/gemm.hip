@@ -418,13 +418,17 @@ template <int BM_, int BN_> struct TileCfg {
   static constexpr int MIN_WAVES_PER_SIMD = (BM_ == 128) ? 2 : 1;
 };
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
+// F8 (T = bf16_t only): fp8 operands as in gemm8p_body -- 128 one-byte elements per k-tile row, the same images and fragment reads,
+// one v_mfma_f32_16x16x128_f8f6f4 per pair of 16-byte fragment reads; 1: activations e4m3, 2: e5m2 (weights always e4m3).
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN, int F8 = 0>
 __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_WAVES_PER_SIMD)) void gemm_kernel(const GemmParams p) {
   using Cfg = TileCfg<BM, BN>;
+  using TO = typename std::conditional<F8 != 0, f8_t, T>::type;     // operand element (addressing)
+  static_assert(F8 == 0 || (sizeof(T) == 2 && !TA && !TB && !ATOMIC), "fp8 operands: K-contiguous, bf16 store epilogue");
   constexpr int NTHREADS = Cfg::NTHREADS, NSTAGE = Cfg::NSTAGE, A_BYTES = Cfg::A_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
   constexpr int MI = Cfg::MI, WM = Cfg::WM;
-  constexpr int BK = TileK<T>::KE;                 // 64 (bf16) / 32 (f32)
-  constexpr int EPC = 16 / (int)sizeof(T);         // elements per 16-byte chunk
+  constexpr int BK = F8 ? 128 : TileK<T>::KE;      // 64 (bf16) / 32 (f32) / 128 (fp8)
+  constexpr int EPC = F8 ? 16 : 16 / (int)sizeof(T);         // elements per 16-byte chunk
   constexpr int TCHA = BM / EPC, TCHB = BN / EPC;  // chunks per TileT row of the A / B image
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
 
@@ -503,15 +507,15 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
 #pragma unroll
       for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
         const int q = tid + NTHREADS * i;
-        if (!TA) { const int r = q >> 3; pa[i] = vaddr<T, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHA; pa[i] = vaddr<T, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
+        if (!TA) { const int r = q >> 3; pa[i] = vaddr<TO, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHA; pa[i] = vaddr<TO, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
         sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
       }
 #pragma unroll
       for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
         const int q = tid + NTHREADS * i;
-        if (!TB) { const int r = q >> 3; pb[i] = vaddr<T, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHB; pb[i] = vaddr<T, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
+        if (!TB) { const int r = q >> 3; pb[i] = vaddr<TO, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHB; pb[i] = vaddr<TO, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
         stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
       }
       until_slow = fast_tiles_after(kt);
@@ -534,6 +538,35 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   auto compute = [&](int stg) {
     const char* sa = smem + stg * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
+    if constexpr (F8 != 0) {
+      typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+      auto cat = [](const Frag<bf16_t>& lo, const Frag<bf16_t>& hi) {
+        const u32x4_t a = __builtin_bit_cast(u32x4_t, lo.v), b = __builtin_bit_cast(u32x4_t, hi.v);
+        return (i32x8_t){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      };
+      Frag<bf16_t> fb[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) frag_load_k(fb[j][ks], sb, wn * 64 + 16 * j + li, ks * 32 + 8 * g);
+#pragma unroll
+      for (int h = 0; h < MI; h += 4) {
+        Frag<bf16_t> fa[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) frag_load_k(fa[i][ks], sa, wm * WM + 16 * (h + i) + li, ks * 32 + 8 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const i32x8_t a8 = cat(fa[i][0], fa[i][1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)      // D[row = n][col = m]: srcA = weights (e4m3), srcB = activations (blgp 0 e4m3 / 1 e5m2)
+            acc[h + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb[j][0], fb[j][1]), a8, acc[h + i][j], 0,
+                                                                             F8 == 2 ? 1 : 0, 0, 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < ((PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32); ++ks) {
       Frag<T> fa[MI], fb[4];
@@ -599,6 +632,13 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
         const int64_t m = m0 + wm * WM + 16 * i + 4 * g + r;
         if (m < p.arow_n) unsafeAtomicAdd(dst + m, p.alpha * accb[i][r]);
       }
+  }
+  if (F8) {                               // per-tensor dequantisation
+    const float sc = p.scale_a[0] * p.scale_b[0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
   gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE);
 }
@@ -1183,6 +1223,16 @@ extern "C" int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* sca
   if ((int64_t)p.tiles_m * p.tiles_n >= (1ll << 31)) return PT_ERR_SHAPE;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, 1);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // short reductions (K < PT_GEMM_F8_8P_MIN_K bytes, default 3072 = 24 k-tiles) on the two-stage 256 x 256 kernel, like bf16
+  static int min8pk = -1;
+  if (min8pk < 0) { const char* e = getenv("PT_GEMM_F8_8P_MIN_K"); min8pk = e ? atoi(e) : 3072; }
+  if (p.K < min8pk) {
+    constexpr int NT256 = TileCfg<256, 256>::NTHREADS;
+    if (a_format == PT_FP8_E4M3) hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, false, 0, 0, 256, 256, 1>), grid, dim3(NT256), 0, s, p);
+    else                         hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, false, 0, 0, 256, 256, 2>), grid, dim3(NT256), 0, s, p);
+    PT_LAUNCH_CHECK();
+    return PT_OK;
+  }
   if (a_format == PT_FP8_E4M3) hipLaunchKernelGGL((gemm8p_f8_kernel<1>), grid, dim3(P8_THREADS), 0, s, p);
   else                         hipLaunchKernelGGL((gemm8p_f8_kernel<2>), grid, dim3(P8_THREADS), 0, s, p);
   PT_LAUNCH_CHECK();

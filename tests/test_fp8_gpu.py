@@ -1,7 +1,7 @@
 """GPU: fp8 path of BASELINE configs[4] -- per-tensor quantisation and the fp8 MFMA GEMM against torch's own float8 dtypes.
 
 The quantiser is checked BYTE-exact against torch (same amax, same scale arithmetic, round-to-nearest-even casts to
-torch.float8_e4m3fn / float8_e5m2); the GEMM against an f32 matmul of the SAME fp8 operands (so only the f32 summation order and
+torch.float8_e4m3fn / float8_e5m2); the GEMM (K < 3072: two-stage 256 x 256 kernel; K >= 3072: eight-phase kernel) against an f32 matmul of the SAME fp8 operands (so only the f32 summation order and
 the bf16 rounding of the output differ: one bf16 ulp per element), and against the unquantised product with the
 tolerance fp8 itself allows (3 mantissa bits: 2^-4 per element, averaged over K)."""
 import pytest
@@ -48,7 +48,7 @@ def test_quantize_bytes_equal_torch_float8(dev, fmt, rows, cols, spread):
 
 
 @pytest.mark.parametrize("a_fmt", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(512, 512, 1024), (768, 1280, 256), (300, 520, 144), (256, 256, 128)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 1024), (768, 1280, 256), (300, 520, 144), (256, 256, 128), (512, 768, 4096), (300, 264, 3088)])
 def test_fp8_gemm_vs_f32_product_of_the_same_fp8_operands(dev, a_fmt, M, N, K):
     from prompt_tts_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
