@@ -204,12 +204,15 @@ int pt_groupnorm_apply(const void* x1, const void* x2, const float* mean, const 
                        const float* gamma, const float* beta, void* y, void* xcat /* raw concat copy or NULL */,
                        int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, float raw_eps, int dtype,
                        pt_stream stream);
-/* backward: ws = f32 [B][G][2] scratch (zeroed by the call unless ws_zeroed).  dx1/dx2 = GN'(dy) [+ dres (concat layout)]. */
+/* backward: ws = f32 [B][G][2] scratch (zeroed by the call unless ws_zeroed).  dx1/dx2 = GN'(dy) [+ dres (concat layout)].
+ * dx_item_sum (may be NULL; C2 must be 0): dx_item_sum[b][c] += sum_n dx1[(b, n)][c], row pitch item_ld floats -- the gradient of
+ * the per-item time-embedding projection a ResnetBlock1D adds before norm2 (resnet.py:255-261), formed inside the slab kernel. */
 int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                      float* dgamma, float* dbeta, float* ws,
                      int64_t B, int64_t N, int64_t C1, int64_t C2, int64_t G, int silu, int accumulate_dx2,
-                     float raw_eps, int ws_zeroed, int n_rep, int64_t rep_stride, int dtype, pt_stream stream);
+                     float raw_eps, int ws_zeroed, int n_rep, int64_t rep_stride, float* dx_item_sum, int64_t item_ld,
+                     int dtype, pt_stream stream);
 
 /* GEGLU (diffusers FeedForward): out[m][j] = proj[m][j] * gelu_erf(proj[m][F + j]),  proj: [M][2F].
  * `bias` (f32 [2F] in the ORIGINAL column order, or NULL) is first added to proj in place.  interleaved != 0: proj / dproj

@@ -109,7 +109,7 @@ SIGNATURES = {
     "pt_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp],
     "pt_groupnorm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _i32, _vp],
     "pt_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                         _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i64, _i32, _vp],
+                         _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i64, _vp, _i64, _i32, _vp],
     "pt_geglu_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "pt_geglu_bwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "pt_silu_fwd": [_vp, _vp, _i64, _i32, _vp],

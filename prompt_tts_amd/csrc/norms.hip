@@ -446,6 +446,7 @@ struct GnSlab {
   bf16_t* y;                                                       // forward
   const bf16_t* dy; const bf16_t* dres; bf16_t* dx1; bf16_t* dx2;     // backward
   float* dgamma; float* dbeta; int acc_dx2, n_rep; int64_t rep_stride; float raw_cnt;
+  float* item_sum; int64_t item_ld;                                 // backward: item_sum[b][c] += sum_n dx[(b, n)][c] (or NULL)
 };
 
 // sum over the lanes of this wave that hold the same column chunk (rows differ in the lane bits above log2(CCH))
@@ -569,6 +570,9 @@ __global__ __launch_bounds__(64 * CCH) void gn_slab_bwd_kernel(const GnSlab p) {
   A /= cnt; Bq /= cnt;
   bf16_t* dbase = first ? p.dx1 + col : p.dx2 + (col - p.C1);
   const bool accum = p.acc_dx2 && !first;
+  float cs[8];                                   // per-item column sums of dx (the time-embedding gradient of a resnet)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int r = r0 + RS * i;
@@ -585,8 +589,24 @@ __global__ __launch_bounds__(64 * CCH) void gn_slab_bwd_kernel(const GnSlab p) {
         if (p.dres) gr += vr.get(e);
         if (accum) gr += old.get(e);
         o.set(e, gr);
+        cs[e] += gr;
       }
       store16(dst, o);
+    }
+  }
+  if (p.item_sum) {                              // this workgroup is the only producer of its item's 8 CCH columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = rows_sum<CCH>(cs[e]);
+    __syncthreads();                             // `red` is reused
+    if (lane < CCH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][8 * cch + e][0] = cs[e];
+    }
+    __syncthreads();
+    if (tid < SC) {
+      float a = 0.f;
+      for (int w = 0; w < NW; ++w) a += red[w][tid][0];
+      unsafeAtomicAdd(p.item_sum + (int64_t)b * p.item_ld + col0 + tid, a);
     }
   }
 }
@@ -784,8 +804,9 @@ extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, 
                                 const float* gamma, const float* beta, const void* dres, void* dx1, void* dx2,
                                 float* dgamma, float* dbeta, float* ws, int64_t B, int64_t N, int64_t C1, int64_t C2,
                                 int64_t G, int silu, int accumulate_dx2, float raw_eps, int ws_zeroed, int n_rep,
-                                int64_t rep_stride, int dtype, pt_stream stream) {
+                                int64_t rep_stride, float* dx_item_sum, int64_t item_ld, int dtype, pt_stream stream) {
   if (B <= 0 || (C2 > 0 && (!x2 || !dx2))) return PT_ERR_SHAPE;
+  if (dx_item_sum && (C2 > 0 || item_ld < C1)) return PT_ERR_ARG;
   if (!pt_aligned16(dy) || !pt_aligned16(x1) || !pt_aligned16(dx1) || (x2 && !pt_aligned16(x2)) ||
       (dx2 && !pt_aligned16(dx2)) || (dres && !pt_aligned16(dres))) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
@@ -798,11 +819,15 @@ extern "C" int pt_groupnorm_bwd(const void* dy, const void* x1, const void* x2, 
     p.eps = raw_eps; p.raw_cnt = raw_eps >= 0.f ? 1.f : 0.f; p.silu = silu;
     p.dy = (const bf16_t*)dy; p.dres = (const bf16_t*)dres; p.dx1 = (bf16_t*)dx1; p.dx2 = (bf16_t*)dx2;
     p.dgamma = dgamma; p.dbeta = dbeta; p.acc_dx2 = accumulate_dx2; p.n_rep = n_rep; p.rep_stride = rep_stride;
+    p.item_sum = dx_item_sum; p.item_ld = item_ld;
     if (cch == 4) GN_SLAB_LAUNCH(gn_slab_bwd_kernel, 4, N, B, s, p); else GN_SLAB_LAUNCH(gn_slab_bwd_kernel, 8, N, B, s, p);
     PT_LAUNCH_CHECK();
     return PT_OK;
   }
-  if (dtype == PT_F32) return gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
-  if (dtype == PT_BF16) return gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
-  return PT_ERR_DTYPE;
+  int st;
+  if (dtype == PT_F32) st = gn_bwd_t<float>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
+  else if (dtype == PT_BF16) st = gn_bwd_t<bf16_t>(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, C1, C2, G, silu, accumulate_dx2, raw_eps, ws_zeroed, n_rep, rep_stride, s);
+  else return PT_ERR_DTYPE;
+  if (st != PT_OK || !dx_item_sum) return st;
+  return pt_colsum(dx1, C1, dx_item_sum, item_ld, B * N, C1, N, 1, 0, dtype, stream);   // two-pass path: a separate segmented sum
 }

@@ -835,13 +835,13 @@ def groupnorm_fwd(x1, x2, gamma, beta, B, N, G, eps, silu, arena=None):
     return y, s
 
 
-def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres=None, arena=None):
+def groupnorm_bwd(dy, x1, x2, s, gamma, beta, ggamma, gbeta, B, N, G, silu, dres=None, arena=None, item_sum=None):
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = arena.alloc(B * G * 2) if arena is not None else torch.empty(B * G * 2, dtype=torch.float32, device=x1.device)
     (ggamma, gbeta), n_rep, rstride = _rep(ggamma, gbeta)
     ops.groupnorm_bwd(dy, x1, x2, s.mean, s.rstd, gamma, beta, dres, dx1, dx2, ggamma, gbeta, ws, B, N, G, silu,
-                      raw_eps=s.raw_eps, ws_zeroed=arena is not None, n_rep=n_rep, rep_stride=rstride)
+                      raw_eps=s.raw_eps, ws_zeroed=arena is not None, n_rep=n_rep, rep_stride=rstride, item_sum=item_sum)
     return dx1, dx2
 
 

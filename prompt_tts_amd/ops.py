@@ -196,11 +196,13 @@ def groupnorm_apply(x1, x2, mean, rstd, gamma, beta, y, xcat, B, N, G, silu, raw
 
 
 def groupnorm_bwd(dy, x1, x2, mean, rstd, gamma, beta, dres, dx1, dx2, dgamma, dbeta, ws, B, N, G, silu,
-                  accumulate_dx2=False, raw_eps=-1.0, ws_zeroed=False, n_rep=1, rep_stride=0):
+                  accumulate_dx2=False, raw_eps=-1.0, ws_zeroed=False, n_rep=1, rep_stride=0, item_sum=None):
+    """item_sum (B, >= C1) f32 or None: item_sum[b][c] += sum_n dx1[(b, n)][c] (a resnet's time-embedding gradient)."""
     C1 = x1.shape[-1]; C2 = x2.shape[-1] if x2 is not None else 0
     check(lib.pt_groupnorm_bwd(_p(dy), _p(x1), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dres), _p(dx1),
                                _p(dx2), _p(dgamma), _p(dbeta), _p(ws), B, N, C1, C2, G, int(silu),
-                               int(accumulate_dx2), raw_eps, int(ws_zeroed), n_rep, rep_stride, pt_dtype(x1), _stream()),
+                               int(accumulate_dx2), raw_eps, int(ws_zeroed), n_rep, rep_stride,
+                               _p(item_sum), item_sum.stride(0) if item_sum is not None else 0, pt_dtype(x1), _stream()),
           "pt_groupnorm_bwd")
 
 

@@ -94,9 +94,10 @@ class ResnetBlock1D(nn.Module):
         da2 = E.conv3_bwd(dout, a2, st.w(self.conv2.weight), st.g(self.conv2.weight), st.g(self.conv2.bias), B, N, N,
                           cin=Cout, cout=Cout)
         dh1, _ = E.groupnorm_bwd(da2, h1, None, s2, st.f(self.norm2.weight), st.f(self.norm2.bias),
-                                 st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True, arena=st.arena_active)
-        # time-embedding projection: d tproj[b][c] = sum_n dh1[(b,n)][c]  (its GEMMs are batched over all blocks by the UNet)
-        ops.colsum(dh1, dtproj, M, Cout, seg_rows=N, ld_out=dtproj.stride(0))
+                                 st.g(self.norm2.weight), st.g(self.norm2.bias), B, N, self.groups, True, arena=st.arena_active,
+                                 item_sum=dtproj)
+        # (item_sum: the time-embedding projection's gradient d tproj[b][c] = sum_n dh1[(b,n)][c] comes out of the GroupNorm
+        # backward itself -- the slab kernel holds the whole item; its GEMMs are batched over all blocks by the UNet)
         # conv1.bias: its gradient is complete here, BEFORE the block is announced to the data-parallel reducer (it rides on
         # the wgrad GEMM's all-ones column like every other bias)
         da1 = E.conv3_bwd(dh1, a1, st.w(self.conv1.weight), st.g(self.conv1.weight), st.g(self.conv1.bias), B, N, N,

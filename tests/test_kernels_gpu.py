@@ -326,10 +326,13 @@ def test_groupnorm_fused_forward_backward(dev, dtype, B, N, C1, C2, G, silu):
     dx1 = torch.empty_like(x1); dx2 = torch.ones_like(x2) if C2 else None
     n_rep, C_al = 4, (C + 63) // 64 * 64
     rep = torch.zeros(2, n_rep, C_al, device=dev); ws = torch.empty(B * G * 2, device=dev)
+    item_sum = torch.full((B, C + 8), 0.5, device=dev)[:, 4:4 + C] if not C2 else None      # a strided view, pre-loaded
     ops.groupnorm_bwd(dy, x1, x2, mean, rstd, gamma.to(dev), beta.to(dev), dres, dx1, dx2, rep[0, 0], rep[1, 0], ws, B, N, G,
-                      silu, accumulate_dx2=True, n_rep=n_rep, rep_stride=C_al)
+                      silu, accumulate_dx2=True, n_rep=n_rep, rep_stride=C_al, item_sum=item_sum)
     dg = rep[0].sum(0)[:C]; db = rep[1].sum(0)[:C]
     dxref = xr.grad.permute(0, 2, 1).reshape(B * N, C) + dresf
+    if item_sum is not None:          # per-item column sums of dx, accumulated into the destination (slab kernel / two-pass + colsum)
+        assert relerr(item_sum - 0.5, dxref.view(B, N, C).sum(1)) < TOL[dtype] * 2
     assert relerr(dx1, dxref[:, :C1]) < TOL[dtype] * 2
     if C2:
         assert relerr(dx2, dxref[:, C1:] + 1.0) < TOL[dtype] * 2
