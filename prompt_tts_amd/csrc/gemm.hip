@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "mma.h"
 
+#ifndef PT_EPI_NT
+#define PT_EPI_NT -1       // tools/gemm_probe.py variant 7 / 8: force non-temporal epilogue stores on / off (-1: GemmParams::nt_store)
+#endif
 #ifndef PT_GEMM_ABLATE
 #define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores, 4 all three (launch floor)
 #endif
@@ -53,6 +56,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int64_t geglu_rows;          // pt_wgrad_group: > 0 = the GEMM's rows are GEGLU-interleaved weight rows (F = geglu_rows)
   const float* scale_a; const float* scale_b;   // pt_gemm_fp8: device-resident dequantisation factors of the two operands
+  int nt_store;                // epilogue rows as non-temporal stores (store_out)
 };
 struct f8_t { uint8_t bits; };   // one fp8 operand element (e4m3 or e5m2): addressing only
 
@@ -112,6 +116,17 @@ __host__ __device__ __forceinline__ int64_t geglu_orig_row(int64_t mi, int64_t F
 }
 
 constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x 128 B per wave
+
+// PT_GEMM_NT=1: output rows leave as NON-TEMPORAL 16-byte stores.  A tile is 128 KiB per CU, i.e. a round of tiles dirties an
+// XCD's whole 4 MiB L2, and the epilogue of a 256 x 256 bf16 tile takes 16.7 us (2 TB/s chip-wide, half of what a plain fill
+// kernel reaches; 63 % of a K = 512 GEMM: tools/gemm_probe.py 0 6).  Streaming past L2 makes the K = 512 GEMMs 7-12 % faster
+// ALONE (tools/gemm_probe.py 0 7) but changes nothing in the training step (43.6 ms either way: the consumer then misses L2),
+// so it is off by default.  Also measured: starting half of the first round's workgroups half a tile period late (to take the
+// CUs out of lock-step) -- no gain, the slow write phase is a per-CU matter, not chip-wide HBM contention.
+__device__ __forceinline__ void store_out(u32x4_t* dst, const u32x4_t v, int nt) {
+  if (PT_EPI_NT >= 0 ? PT_EPI_NT : nt) __builtin_nontemporal_store(v, dst);
+  else *dst = v;
+}
 
 // ---- epilogue (shared by both kernels): acc[i][j] is the 16x16 tile at rows 16 i, columns 16 j of the wave's
 // (16 MI) x 64 sub-tile whose origin is (m0 + wm * 16 MI, n0 + wn * 64); `scratch` = 2 KiB of wave-private LDS ----------
@@ -232,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int r = 8 * it + rd_row;
-            *reinterpret_cast<u32x4_t*>(Cb + r * p.ldc) = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+            store_out(reinterpret_cast<u32x4_t*>(Cb + r * p.ldc), *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4)), p.nt_store);
           }
         }
         continue;
@@ -276,7 +291,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
         {
           const int r = lane >> 2, c = lane & 3;               // 16 rows x 64 bytes: one pass, 16 bytes per lane
           bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C2) + (mbase + 16 * i + r) * p.ldc2 + (nbase >> 1) + 8 * c;
-          *reinterpret_cast<u32x4_t*>(Cb) = *reinterpret_cast<const u32x4_t*>(scratch + r * 64 + ((c ^ (r & 3)) << 4));
+          store_out(reinterpret_cast<u32x4_t*>(Cb), *reinterpret_cast<const u32x4_t*>(scratch + r * 64 + ((c ^ (r & 3)) << 4)), p.nt_store);
         }
       }
       for (int op = 0; op < ((p.C2 && p.act != 2) ? 2 : 1); ++op) {
@@ -296,7 +311,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int r = 8 * it + rd_row;
-          *reinterpret_cast<u32x4_t*>(Cb + r * ld) = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+          const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+          store_out(reinterpret_cast<u32x4_t*>(Cb + r * ld), ov, p.nt_store);
         }
       }
     }
@@ -1186,6 +1202,7 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
   p.tiles_m = p.tiles_n = 0;   // set per tile configuration at launch
   p.geglu_rows = d->geglu_rows;
   p.scale_a = p.scale_b = nullptr;
+  { static int nt = -1; if (nt < 0) { const char* e = getenv("PT_GEMM_NT"); nt = e ? atoi(e) : 0; } p.nt_store = nt; }
   if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
   if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
   if (d->act >= 2) {

@@ -21,7 +21,8 @@ SHAPES = [("lin K512 N512", 32768, 512, 512), ("lin K512 N1536", 32768, 1536, 51
 def build(ablate):
     out = f"/tmp/libgemm_ab{ablate}.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                    f"-DPT_GEMM_ABLATE={ablate}", os.path.join(SRC, "gemm.hip"), "-o", out], check=True)
+                    f"-DPT_GEMM_ABLATE={0 if ablate >= 7 else ablate}", f"-DPT_EPI_NT={1 if ablate == 7 else (0 if ablate == 8 else -1)}",
+                    os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "capi.hip"), "-o", out], check=True)
     lib = C.CDLL(out)
     lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]
     lib.pt_gemm.restype = C.c_int
