@@ -124,6 +124,7 @@ constexpr int SCRATCH_PER_WAVE = 2048;  // epilogue transpose scratch: 16 rows x
 // so it is off by default.  Also measured: starting half of the first round's workgroups half a tile period late (to take the
 // CUs out of lock-step) -- no gain, the slow write phase is a per-CU matter, not chip-wide HBM contention.
 __device__ __forceinline__ void store_out(u32x4_t* dst, const u32x4_t v, int nt) {
+  if (PT_GEMM_ABLATE == 9) { asm volatile("" ::"v"(v)); return; }      // probe: the whole epilogue but its global stores
   if (PT_EPI_NT >= 0 ? PT_EPI_NT : nt) __builtin_nontemporal_store(v, dst);
   else *dst = v;
 }
@@ -180,6 +181,101 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
     const int wr_off = li * 128 + ((g & 1) << 3);            // scratch write: row li, 8-byte half (g&1) of chunk 2j + (g>>1)
     const int rd_row = lane >> 3, rd_c = lane & 7;           // scratch read: rows rd_row, rd_row + 8; chunk rd_c
     const bool has_alpha = p.alpha != 1.0f;
+    // LOAD PASS, in place on the accumulators, BEFORE the first store of the tile: alpha, bias (loaded once, it does not depend
+    // on the row block), row bias and residuals.  gfx950 has ONE counter for loads and stores (vmcnt), so a load issued after a
+    // store can only be waited for together with that store's acknowledgement from memory: with the loads inside the store
+    // loop every 16-row block stalled on the previous block's write round trip (the epilogue of a 256 x 256 tile took 16.7 us).
+    {
+      f32x4_t bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          // act 2: output columns are GEGLU-interleaved (64 q + t: t < 32 value row 32 q + t, else gate row F + 32 q + t - 32)
+          const int64_t bcol = p.act == 2 ? (j < 2 ? (nbase >> 1) + 16 * j : (p.N >> 1) + (nbase >> 1) + 16 * (j - 2)) : nbase + 16 * j;
+          bv[j] = *reinterpret_cast<const f32x4_t*>(p.bias + bcol + 4 * g);
+        }
+      }
+      const bool res1 = p.residual != nullptr && p.act != 3;      // act 3 reads its "residual" (the saved projection) itself
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int64_t m = mbase + 16 * i + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (has_alpha) acc[i][j] *= p.alpha;
+          acc[i][j] += bv[j];
+        }
+        if (p.row_bias) {
+          const float* rb = p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld + nbase + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
+        }
+        if (res1) {
+          const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr + nbase + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
+            acc[i][j][0] += __uint_as_float(t[0] << 16); acc[i][j][1] += __uint_as_float(t[0] & 0xffff0000u);
+            acc[i][j][2] += __uint_as_float(t[1] << 16); acc[i][j][3] += __uint_as_float(t[1] & 0xffff0000u);
+          }
+        }
+        if (p.residual2) {
+          const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual2) + m * p.ldr2 + nbase + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
+            acc[i][j][0] += __uint_as_float(t[0] << 16); acc[i][j][1] += __uint_as_float(t[0] & 0xffff0000u);
+            acc[i][j][2] += __uint_as_float(t[1] << 16); acc[i][j][3] += __uint_as_float(t[1] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    // STORE PASS.  The unrolled epilogue is straight-line code every wave executes ONCE per tile, so its size is its cost: with
+    // every variant (ELU, second output, GEGLU forward / backward) inlined in one body the pass was ~45 KB of instructions and
+    // ran at instruction-fetch speed -- 11 us per 256 x 256 tile even with the global stores compiled out (tools/gemm_probe.py
+    // 0 9 6), 40 % of a K = 512 GEMM.  The plain case (one output, no activation: most launches) therefore has its own compact
+    // body; ELU gets a copy; the GEGLU / two-output variants share the general body below.
+    if (p.act <= 1 && !p.C2) {
+      bf16_t* Cb0 = reinterpret_cast<bf16_t*>(p.C) + (mbase + rd_row) * p.ldc + nbase + 8 * rd_c;
+      const int64_t step8 = 8 * p.ldc;
+      if (p.act == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u32x2_t o;
+            o[0] = (uint32_t)f32_to_bf16_bits(acc[i][j][0]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(acc[i][j][2]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][3]) << 16);
+            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+          }
+          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(scratch + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          store_out(reinterpret_cast<u32x4_t*>(Cb0), o0, p.nt_store);
+          store_out(reinterpret_cast<u32x4_t*>(Cb0 + step8), o1, p.nt_store);
+          Cb0 += 2 * step8;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = acc[i][j][r] < 0.f ? (__expf(acc[i][j][r]) - 1.f) : acc[i][j][r];
+            u32x2_t o;
+            o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+          }
+          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(scratch + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          store_out(reinterpret_cast<u32x4_t*>(Cb0), o0, p.nt_store);
+          store_out(reinterpret_cast<u32x4_t*>(Cb0 + step8), o1, p.nt_store);
+          Cb0 += 2 * step8;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int64_t m = mbase + 16 * i + li;
@@ -188,29 +284,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
-      if (has_alpha) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[j][r] *= p.alpha;
-      }
-      if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // act 2: output columns are GEGLU-interleaved (64 q + t: t < 32 value row 32 q + t, else gate row F + 32 q + t - 32)
-          const int64_t bcol = p.act == 2 ? (j < 2 ? (nbase >> 1) + 16 * j : (p.N >> 1) + (nbase >> 1) + 16 * (j - 2)) : nbase + 16 * j;
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.bias + bcol + 4 * g);
-          v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
-        }
-      }
-      if (p.row_bias) {
-        const float* rb = p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld + nbase + 4 * g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
-          v[j][0] += t[0]; v[j][1] += t[1]; v[j][2] += t[2]; v[j][3] += t[3];
-        }
-      }
       if (p.act == 3) {
         // GEGLU backward fused into the ff2 dgrad: the tile holds d(act)[m][jc]; with value / gate read from the saved
         // (interleaved) projection, C receives d(proj) in the same interleaved layout: per 32-column block q of act,
@@ -251,24 +324,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
           }
         }
         continue;
-      }
-      if (p.residual) {
-        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr + nbase + 4 * g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
-          v[j][0] += __uint_as_float(t[0] << 16); v[j][1] += __uint_as_float(t[0] & 0xffff0000u);
-          v[j][2] += __uint_as_float(t[1] << 16); v[j][3] += __uint_as_float(t[1] & 0xffff0000u);
-        }
-      }
-      if (p.residual2) {
-        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual2) + m * p.ldr2 + nbase + 4 * g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
-          v[j][0] += __uint_as_float(t[0] << 16); v[j][1] += __uint_as_float(t[0] & 0xffff0000u);
-          v[j][2] += __uint_as_float(t[1] << 16); v[j][3] += __uint_as_float(t[1] & 0xffff0000u);
-        }
       }
       if (p.act == 2) {
         // GEGLU forward fused into the ff1 GEMM: columns are interleaved so that register block j (value) and j + 2 (gate)
@@ -638,7 +693,13 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
     __syncthreads();
   }
 
-  if (PT_GEMM_ABLATE == 6) return;      // probe: everything but the epilogue code
+  if (PT_GEMM_ABLATE == 6) {             // probe: everything but the epilogue code (accumulators kept live: no dead MFMAs)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   if (ATOMIC && do_sum && li == 0) {     // column 0 of the ones product: rows 4g + r of each 16-row block
     float* dst = p.arow_sum + (int64_t)(blockIdx.x % p.arow_rep) * p.arow_stride;
 #pragma unroll
