@@ -276,36 +276,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       }
       return;
     }
+if (p.act == 3) {
+      // GEGLU backward fused into the ff2 dgrad: the tile holds d(act)[m][jc]; with value / gate read from the saved
+      // (interleaved) projection, C receives d(proj) in the same interleaved layout: per 32-column block q of act,
+      // 64 output columns [d value (32) | d gate (32)] -- one whole 128-byte row segment per block.  The projection values of
+      // row block i + 1 are requested BEFORE row block i is stored (loads behind stores wait for the stores: one vmcnt).
+      u32x2_t hv[2][2][2], gv[2][2][2];                    // [parity][h][jj]
+      auto fetch = [&](int i, int par) {
+        const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.residual) + (mbase + 16 * i + li) * p.ldr;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int64_t m = mbase + 16 * i + li;
-      float v[4][4];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int jj = 0; jj < 2; ++jj) {
+            hv[par][h][jj] = *reinterpret_cast<const u32x2_t*>(pr + 2 * nbase + 64 * h + 16 * jj + 4 * g);
+            gv[par][h][jj] = *reinterpret_cast<const u32x2_t*>(pr + 2 * nbase + 64 * h + 32 + 16 * jj + 4 * g);
+          }
+      };
+      fetch(0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
-      if (p.act == 3) {
-        // GEGLU backward fused into the ff2 dgrad: the tile holds d(act)[m][jc]; with value / gate read from the saved
-        // (interleaved) projection, C receives d(proj) in the same interleaved layout: per 32-column block q of act,
-        // 64 output columns [d value (32) | d gate (32)] -- one whole 128-byte row segment per block.
-        const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr;
+      for (int i = 0; i < MI; ++i) {
+        if (i + 1 < MI) fetch(i + 1, (i + 1) & 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int64_t q64 = 2 * nbase + 64 * h;                  // first interleaved column of this 32-column block
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
-            const u32x2_t hv = *reinterpret_cast<const u32x2_t*>(pr + q64 + 16 * jj + 4 * g);
-            const u32x2_t gv = *reinterpret_cast<const u32x2_t*>(pr + q64 + 32 + 16 * jj + 4 * g);
-            const float val[4] = {__uint_as_float(hv[0] << 16), __uint_as_float(hv[0] & 0xffff0000u),
-                                  __uint_as_float(hv[1] << 16), __uint_as_float(hv[1] & 0xffff0000u)};
-            const float gat[4] = {__uint_as_float(gv[0] << 16), __uint_as_float(gv[0] & 0xffff0000u),
-                                  __uint_as_float(gv[1] << 16), __uint_as_float(gv[1] & 0xffff0000u)};
+            const u32x2_t hw = hv[i & 1][h][jj], gw = gv[i & 1][h][jj];
+            const float val[4] = {__uint_as_float(hw[0] << 16), __uint_as_float(hw[0] & 0xffff0000u),
+                                  __uint_as_float(hw[1] << 16), __uint_as_float(hw[1] & 0xffff0000u)};
+            const float gat[4] = {__uint_as_float(gw[0] << 16), __uint_as_float(gw[0] & 0xffff0000u),
+                                  __uint_as_float(gw[1] << 16), __uint_as_float(gw[1] & 0xffff0000u)};
             float dv[4], dg[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float ge, dge;
               gelu_erf_fast(gat[r], ge, dge);
-              const float d = v[2 * h + jj][r];
+              const float d = acc[i][2 * h + jj][r];
               dv[r] = d * ge; dg[r] = d * val[r] * dge;
             }
             u32x2_t o;
@@ -323,20 +329,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
             store_out(reinterpret_cast<u32x4_t*>(Cb + r * p.ldc), *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4)), p.nt_store);
           }
         }
-        continue;
       }
-      if (p.act == 2) {
-        // GEGLU forward fused into the ff1 GEMM: columns are interleaved so that register block j (value) and j + 2 (gate)
-        // of one lane belong to the same act column: C2[m][nbase / 2 + 16 j + 4 g + r] = value * gelu(gate); the raw
-        // projection tile still goes to C below (the backward needs it)
+      return;
+    }
+    if (p.act == 2) {
+      // GEGLU forward fused into the ff1 GEMM: columns are interleaved so that register block j (value) and j + 2 (gate)
+      // of one lane belong to the same act column: C2[m][nbase / 2 + 16 j + 4 g + r] = value * gelu(gate); the raw
+      // projection tile goes to C as well (the backward needs it)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           float w[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float ge, dge;
-            gelu_erf_fast(v[jj + 2][r], ge, dge);
-            w[r] = v[jj][r] * ge;
+            gelu_erf_fast(acc[i][jj + 2][r], ge, dge);
+            w[r] = acc[i][jj][r] * ge;
           }
           u32x2_t o;
           o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
@@ -348,8 +357,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
           bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C2) + (mbase + 16 * i + r) * p.ldc2 + (nbase >> 1) + 8 * c;
           store_out(reinterpret_cast<u32x4_t*>(Cb), *reinterpret_cast<const u32x4_t*>(scratch + r * 64 + ((c ^ (r & 3)) << 4)), p.nt_store);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x2_t o;
+          o[0] = (uint32_t)f32_to_bf16_bits(acc[i][j][0]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][1]) << 16);
+          o[1] = (uint32_t)f32_to_bf16_bits(acc[i][j][2]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][3]) << 16);
+          *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+        }
+        bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C) + (mbase + 16 * i) * p.ldc + nbase + 8 * rd_c;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = 8 * it + rd_row;
+          store_out(reinterpret_cast<u32x4_t*>(Cb + r * p.ldc), *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4)), p.nt_store);
+        }
       }
-      for (int op = 0; op < ((p.C2 && p.act != 2) ? 2 : 1); ++op) {
+      return;
+    }
+    // two outputs (C, C2) with their own activations (Encodec decoder: raw + ELU copy)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
+      for (int op = 0; op < (p.C2 ? 2 : 1); ++op) {
         const int act = op == 0 ? p.act : p.act2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
