@@ -198,35 +198,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       }
       const bool res1 = p.residual != nullptr && p.act != 3;      // act 3 reads its "residual" (the saved projection) itself
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int64_t m = mbase + 16 * i + li;
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (has_alpha) acc[i][j] *= p.alpha;
           acc[i][j] += bv[j];
         }
-        if (p.row_bias) {
-          const float* rb = p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld + nbase + 4 * g;
+      // each optional operand in ONE branch, its loads issued in batches of four row blocks and only then consumed (inside a
+      // per-row-block `if` the compiler waits for every block's loads before it issues the next block's: 8 memory round trips)
+      auto add_bf16_rows = [&](const char* base, int64_t ld) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
-        }
-        if (res1) {
-          const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + m * p.ldr + nbase + 4 * g;
+        for (int i0 = 0; i0 < MI; i0 += 4) {
+          u32x2_t t[4][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
-            acc[i][j][0] += __uint_as_float(t[0] << 16); acc[i][j][1] += __uint_as_float(t[0] & 0xffff0000u);
-            acc[i][j][2] += __uint_as_float(t[1] << 16); acc[i][j][3] += __uint_as_float(t[1] & 0xffff0000u);
+          for (int i = 0; i < 4; ++i) {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(base) + (mbase + 16 * (i0 + i) + li) * ld + nbase + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
           }
-        }
-        if (p.residual2) {
-          const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual2) + m * p.ldr2 + nbase + 4 * g;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rp + 16 * j);
-            acc[i][j][0] += __uint_as_float(t[0] << 16); acc[i][j][1] += __uint_as_float(t[0] & 0xffff0000u);
-            acc[i][j][2] += __uint_as_float(t[1] << 16); acc[i][j][3] += __uint_as_float(t[1] & 0xffff0000u);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[i0 + i][j][0] += __uint_as_float(t[i][j][0] << 16); acc[i0 + i][j][1] += __uint_as_float(t[i][j][0] & 0xffff0000u);
+              acc[i0 + i][j][2] += __uint_as_float(t[i][j][1] << 16); acc[i0 + i][j][3] += __uint_as_float(t[i][j][1] & 0xffff0000u);
+            }
+        }
+      };
+      if (res1) add_bf16_rows(p.residual, p.ldr);
+      if (p.residual2) add_bf16_rows(p.residual2, p.ldr2);
+      if (p.row_bias) {
+#pragma unroll
+        for (int i0 = 0; i0 < MI; i0 += 2) {
+          f32x4_t t[2][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int64_t m = mbase + 16 * (i0 + i) + li;
+            const float* rb = p.row_bias + (m / p.row_bias_rows) * p.row_bias_ld + nbase + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const f32x4_t*>(rb + 16 * j);
           }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] += t[i][j];
         }
       }
     }
