@@ -21,6 +21,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
   return __builtin_bit_cast(uint16_t, h);
 }
+// two f32 -> one dword of two bf16 (low half = a): ONE v_cvt_pk_bf16_f32 (converting singly costs a shift and an or per pair)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
+  const bf16x2_v h = __builtin_convertvector((f32x2_v){a, b}, bf16x2_v);
+  return __builtin_bit_cast(uint32_t, h);
+}
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return bf16_bits_to_f32(x.bits); }
@@ -66,8 +73,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float a, flo
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
   u32x2_t o;
-  o[0] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
-  o[1] = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  o[0] = pack_bf16x2(a, b);
+  o[1] = pack_bf16x2(c, d);
   *reinterpret_cast<u32x2_t*>(p) = o;
 }
 

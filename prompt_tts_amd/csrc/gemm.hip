@@ -259,8 +259,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             u32x2_t o;
-            o[0] = (uint32_t)f32_to_bf16_bits(acc[i][j][0]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(acc[i][j][2]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][3]) << 16);
+            o[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+            o[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
             *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
           }
           const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
@@ -278,8 +278,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = acc[i][j][r] < 0.f ? (__expf(acc[i][j][r]) - 1.f) : acc[i][j][r];
             u32x2_t o;
-            o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+            o[0] = pack_bf16x2(w[0], w[1]);
+            o[1] = pack_bf16x2(w[2], w[3]);
             *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
           }
           const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
@@ -330,11 +330,11 @@ if (p.act == 3) {
               dv[r] = d * ge; dg[r] = d * val[r] * dge;
             }
             u32x2_t o;
-            o[0] = (uint32_t)f32_to_bf16_bits(dv[0]) | ((uint32_t)f32_to_bf16_bits(dv[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(dv[2]) | ((uint32_t)f32_to_bf16_bits(dv[3]) << 16);
+            o[0] = pack_bf16x2(dv[0], dv[1]);
+            o[1] = pack_bf16x2(dv[2], dv[3]);
             *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * jj + (g >> 1)) ^ (li & 7)) << 4)) = o;
-            o[0] = (uint32_t)f32_to_bf16_bits(dg[0]) | ((uint32_t)f32_to_bf16_bits(dg[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(dg[2]) | ((uint32_t)f32_to_bf16_bits(dg[3]) << 16);
+            o[0] = pack_bf16x2(dg[0], dg[1]);
+            o[1] = pack_bf16x2(dg[2], dg[3]);
             *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((4 + 2 * jj + (g >> 1)) ^ (li & 7)) << 4)) = o;
           }
           bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C) + (mbase + 16 * i) * p.ldc + q64 + 8 * rd_c;
@@ -363,8 +363,8 @@ if (p.act == 3) {
             w[r] = acc[i][jj][r] * ge;
           }
           u32x2_t o;
-          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
-          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          o[0] = pack_bf16x2(w[0], w[1]);
+          o[1] = pack_bf16x2(w[2], w[3]);
           *reinterpret_cast<u32x2_t*>(scratch + li * 64 + (((2 * jj + (g >> 1)) ^ (li & 3)) << 4) + ((g & 1) << 3)) = o;
         }
         {
@@ -375,8 +375,8 @@ if (p.act == 3) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           u32x2_t o;
-          o[0] = (uint32_t)f32_to_bf16_bits(acc[i][j][0]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][1]) << 16);
-          o[1] = (uint32_t)f32_to_bf16_bits(acc[i][j][2]) | ((uint32_t)f32_to_bf16_bits(acc[i][j][3]) << 16);
+          o[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+          o[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
           *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
         }
         bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C) + (mbase + 16 * i) * p.ldc + nbase + 8 * rd_c;
@@ -404,8 +404,8 @@ if (p.act == 3) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
           u32x2_t o;
-          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
-          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          o[0] = pack_bf16x2(w[0], w[1]);
+          o[1] = pack_bf16x2(w[2], w[3]);
           *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
         }
         bf16_t* Cb = reinterpret_cast<bf16_t*>(op == 0 ? p.C : p.C2) + (mbase + 16 * i) * (op == 0 ? p.ldc : p.ldc2) + nbase + 8 * rd_c;
@@ -466,8 +466,8 @@ if (p.act == 3) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
           u32x2_t o;
-          o[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
-          o[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+          o[0] = pack_bf16x2(w[0], w[1]);
+          o[1] = pack_bf16x2(w[2], w[3]);
           const int chunk = 2 * j + (g >> 1);
           *reinterpret_cast<u32x2_t*>(scratch + li * 128 + ((chunk ^ (li & 7)) << 4) + ((g & 1) << 3)) = o;
         }
