@@ -573,25 +573,39 @@ __global__ __launch_bounds__(64 * CCH) void gn_slab_bwd_kernel(const GnSlab p) {
   float cs[8];                                   // per-item column sums of dx (the time-embedding gradient of a resnet)
 #pragma unroll
   for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  // The residual gradient / the accumulated destination are fetched in groups of GRP rows AHEAD of the stores: gfx950 counts
+  // loads and stores in one counter (vmcnt), so a load issued behind a store is only complete when that store is; fetched row by
+  // row inside the store loop every row waited for the previous row's write round trip.
+  constexpr int GRP = NCH < 4 ? NCH : 4;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int r = r0 + RS * i;
-    if (r < p.N) {
-      const int64_t row = (int64_t)b * p.N + r;
-      V vr, old, o;
-      if (p.dres) vr = load16(p.dres + row * p.C + col);
-      bf16_t* dst = dbase + row * ld;
-      if (accum) old = load16(dst);
+  for (int i0 = 0; i0 < NCH; i0 += GRP) {
+    V vr[GRP], old[GRP];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = vx[i].get(e), dz = vd[i].get(e);
-        float gr = rs * (dz * ga[e] - A - xh * Bq);
-        if (p.dres) gr += vr.get(e);
-        if (accum) gr += old.get(e);
-        o.set(e, gr);
-        cs[e] += gr;
+    for (int k = 0; k < GRP; ++k) {
+      const int r = r0 + RS * (i0 + k);
+      if (r < p.N) {
+        const int64_t row = (int64_t)b * p.N + r;
+        if (p.dres) vr[k] = load16(p.dres + row * p.C + col);
+        if (accum) old[k] = load16(dbase + row * ld);
       }
-      store16(dst, o);
+    }
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) {
+      const int i = i0 + k, r = r0 + RS * i;
+      if (r < p.N) {
+        const int64_t row = (int64_t)b * p.N + r;
+        V o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = vx[i].get(e), dz = vd[i].get(e);
+          float gr = rs * (dz * ga[e] - A - xh * Bq);
+          if (p.dres) gr += vr[k].get(e);
+          if (accum) gr += old[k].get(e);
+          o.set(e, gr);
+          cs[e] += gr;
+        }
+        store16(dbase + row * ld, o);
+      }
     }
   }
   if (p.item_sum) {                              // this workgroup is the only producer of its item's 8 CCH columns
