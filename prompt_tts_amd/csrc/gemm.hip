@@ -133,7 +133,12 @@ __device__ __forceinline__ void store_out(u32x4_t* dst, const u32x4_t v, int nt)
 // (16 MI) x 64 sub-tile whose origin is (m0 + wm * 16 MI, n0 + wn * 64); `scratch` = 2 KiB of wave-private LDS ----------
 template <typename T, bool ATOMIC, int MI, int BM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], const int64_t m0, const int64_t n0,
-                                              const int wm, const int wn, const int lane, char* scratch) {
+                                              const int wm, const int wn, const int lane, char* scratch0,
+                                              const int scr_stride = 0) {
+  // scr_stride: bytes between the transposition scratch of consecutive 16-row blocks (0: one 2 KiB scratch reused by all of
+  // them).  The callers pass the dead operand stages (2 KiB per row block per wave): with private scratch per block there is no
+  // write-after-read wait between blocks and the compiler overlaps one block's LDS round trip with the next block's conversions.
+  char* scratch = scratch0;
   constexpr int WM = 16 * MI;
   const int g = lane >> 4, li = lane & 15;
   if (ATOMIC) {
@@ -251,20 +256,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
     // 0 9 6), 40 % of a K = 512 GEMM.  The plain case (one output, no activation: most launches) therefore has its own compact
     // body; ELU gets a copy; the GEGLU / two-output variants share the general body below.
     if (p.act <= 1 && !p.C2) {
+      // (per-row-block scratch: sc = scratch0 + i * scr_stride)
       bf16_t* Cb0 = reinterpret_cast<bf16_t*>(p.C) + (mbase + rd_row) * p.ldc + nbase + 8 * rd_c;
       const int64_t step8 = 8 * p.ldc;
-      if (p.act == 0) {
+      if (PT_GEMM_ABLATE == 10) {                      // probe: no LDS transposition, 8-byte stores straight from the accumulators
+        bf16_t* Cd = reinterpret_cast<bf16_t*>(p.C) + (mbase + li) * p.ldc + nbase + 4 * g;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             u32x2_t o;
             o[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
             o[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+            *reinterpret_cast<u32x2_t*>(Cd + (int64_t)16 * i * p.ldc + 16 * j) = o;
           }
-          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
-          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(scratch + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+        return;
+      }
+      if (p.act == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          char* sc = scratch0 + i * scr_stride;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u32x2_t o;
+            o[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+            o[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<u32x2_t*>(sc + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+          }
+          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(sc + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(sc + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
           store_out(reinterpret_cast<u32x4_t*>(Cb0), o0, p.nt_store);
           store_out(reinterpret_cast<u32x4_t*>(Cb0 + step8), o1, p.nt_store);
           Cb0 += 2 * step8;
@@ -272,6 +292,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+          char* sc = scratch0 + i * scr_stride;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float w[4];
@@ -280,10 +301,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
             u32x2_t o;
             o[0] = pack_bf16x2(w[0], w[1]);
             o[1] = pack_bf16x2(w[2], w[3]);
-            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+            *reinterpret_cast<u32x2_t*>(sc + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
           }
-          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(scratch + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
-          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(scratch + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(sc + rd_row * 128 + ((rd_c ^ (rd_row & 7)) << 4));
+          const u32x4_t o1 = *reinterpret_cast<const u32x4_t*>(sc + (8 + rd_row) * 128 + ((rd_c ^ (rd_row & 7)) << 4));
           store_out(reinterpret_cast<u32x4_t*>(Cb0), o0, p.nt_store);
           store_out(reinterpret_cast<u32x4_t*>(Cb0 + step8), o1, p.nt_store);
           Cb0 += 2 * step8;
@@ -310,6 +331,7 @@ if (p.act == 3) {
       fetch(0, 0);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        scratch = scratch0 + i * scr_stride;
         if (i + 1 < MI) fetch(i + 1, (i + 1) & 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -353,6 +375,7 @@ if (p.act == 3) {
       // projection tile goes to C as well (the backward needs it)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        scratch = scratch0 + i * scr_stride;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           float w[4];
@@ -764,7 +787,9 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
-  gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_PER_WAVE);
+  // every wave is past the loop's last barrier: the operand stages are dead and serve as per-row-block transposition scratch
+  static_assert(Cfg::NWAVES * MI * SCRATCH_PER_WAVE <= NSTAGE * STAGE_BYTES, "stages hold one scratch per row block per wave");
+  gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + wave * (MI * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
 }
 
 // =====================================================================================================================
@@ -1052,7 +1077,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
-  gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * SCRATCH_PER_WAVE);
+  gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * (8 * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
 }
 
 __device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
