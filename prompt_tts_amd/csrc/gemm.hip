@@ -61,6 +61,17 @@ struct GemmParams {
 struct f8_t { uint8_t bits; };   // one fp8 operand element (e4m3 or e5m2): addressing only
 
 __device__ __attribute__((aligned(256))) const uint32_t pt_zero_page[64] = {0};
+#ifndef PT_GEMM_TRACE
+#define PT_GEMM_TRACE 0       // tools/gemm_probe.py --trace: wave 0 of workgroup 0 leaves s_memtime stamps in pt_trace
+#endif
+#if PT_GEMM_TRACE
+__device__ unsigned long long pt_trace[8];
+#endif
+#if PT_GEMM_TRACE
+#define PT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pt_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(1))) const void pt_gptr;
 typedef __attribute__((address_space(3))) void pt_lptr;
@@ -250,6 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
         }
       }
     }
+    PT_STAMP(4);
     // STORE PASS.  The unrolled epilogue is straight-line code every wave executes ONCE per tile, so its size is its cost: with
     // every variant (ELU, second output, GEGLU forward / backward) inlined in one body the pass was ~45 KB of instructions and
     // ran at instruction-fetch speed -- 11 us per 256 x 256 tile even with the global stores compiled out (tools/gemm_probe.py
@@ -574,6 +586,7 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
 
   if (PT_GEMM_ABLATE == 5) return;      // probe: pure dispatch cost
+  PT_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;     // WAVES_M x WAVES_N waves of WM x 64
   const int g = lane >> 4, li = lane & 15;
@@ -737,7 +750,9 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   };
   if (NSTAGE == 2) {
     stage(kt_begin, 0);
+    PT_STAMP(1);
     __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
+    PT_STAMP(2);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
@@ -787,9 +802,11 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
+  PT_STAMP(3);
   // every wave is past the loop's last barrier: the operand stages are dead and serve as per-row-block transposition scratch
   static_assert(Cfg::NWAVES * MI * SCRATCH_PER_WAVE <= NSTAGE * STAGE_BYTES, "stages hold one scratch per row block per wave");
   gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + wave * (MI * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
+  PT_STAMP(5);
 }
 
 // =====================================================================================================================
@@ -1388,6 +1405,12 @@ extern "C" int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* sca
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
+
+#if PT_GEMM_TRACE
+extern "C" int pt_debug_gemm_trace(unsigned long long* out8) {       // diagnostic builds only (tools/gemm_probe.py --trace)
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_trace), sizeof(unsigned long long) * 8) == hipSuccess ? PT_OK : PT_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int64_t pt_wgrad_group_ws_floats(int target_wgs) {
   return (int64_t)(target_wgs > 0 ? target_wgs : 256) * 256 * 256;

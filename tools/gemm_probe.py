@@ -123,6 +123,20 @@ if __name__ == "__main__":
                 row += f"{us:9.1f}/{2.0 * T * NO * KI / us / 1e6:6.0f}".rjust(18)
             print(row, flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--trace":    # s_memtime stamps of wave 0 / workgroup 0 (100 MHz counter: 10 ns units)
+        out = "/tmp/libgemm_trace.so"
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPT_GEMM_TRACE=1",
+                        os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "capi.hip"), "-o", out], check=True)
+        lib = C.CDLL(out)
+        lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
+        buf = (C.c_ulonglong * 8)()
+        for name, M, N, K in SHAPES[:3]:
+            run(lib, M, N, K, iters=5)
+            torch.cuda.synchronize()
+            lib.pt_debug_gemm_trace(buf)
+            t = [int(buf[i]) for i in range(6)]
+            print(name, "stamps (x10 ns) relative to entry:", [x - t[0] for x in t], flush=True)
+        sys.exit(0)
     variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]
     libs = {v: build(v) for v in variants}
     print("shape".ljust(18) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
