@@ -261,6 +261,13 @@ def sample_bench(model, batch, wl, n_steps=10):
             "audio_s_per_s_at_1000_steps": wl["B"] * wl["T"] / 75.0 / (per * 1000), "timed_steps": n_steps}
 
 
+def self_launch(n, argv=None, script=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children of torch.distributed.run (one per GPU, rendezvous
+    on 127.0.0.1), let rank 0's JSON line through on stdout, return the launcher's exit code (non-zero if any rank failed)."""
+    from prompt_tts_amd.launch import spawn_ranks
+    return spawn_ranks(n, script or os.path.abspath(__file__), sys.argv[1:] if argv is None else argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,15 +282,17 @@ def main():
     ap.add_argument("--kernel-timing", action="store_true", help="per-symbol HIP-event timing of one extra step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one command, N ranks (the reference is launched once and fans out: train.py:25-29, README.md:36-42).  The children are
+        # FRESH processes started before this one has made any torch.cuda / HIP call; this process never touches the GPU.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")        # "gloo": rehearsal of the N>1 path on a single GPU
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1) if backend == "gloo" else local
+    from prompt_tts_amd.launch import local_device_index
+    local = local_device_index(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -362,6 +371,20 @@ def main():
                      "flops_per_token": 3 * fwd_flops / (wl["n_q"] * wl["T"])},
     }
     note(f"timed {args.steps} steps: {wall / args.steps * 1e3:.1f} ms/step")
+    if world > 1:
+        # what the collective cost and how much of it backward hid: one extra step with HIP events on the communication stream
+        out["nccl_ranks"] = dist.get_world_size()           # the world size the process group (RCCL) reports
+        out["backend"] = dist.get_backend()
+        reducer.timing = True
+        step(); torch.cuda.synchronize()
+        tm = reducer.timing_ms()
+        reducer.timing = False
+        if tm is not None:
+            tt = torch.tensor([tm["allreduce_ms"], tm["exposed_ms"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out["allreduce_ms"] = float(tt[0]); out["allreduce_exposed_ms"] = float(tt[1])
+            out["allreduce_overlap_pct"] = 100.0 * (1.0 - float(tt[1]) / float(tt[0])) if float(tt[0]) > 0 else 0.0
+            out["allreduce_buckets"] = tm["buckets"]; out["allreduce_bytes_per_step"] = tm["bytes"]
     if rank == 0 and world == 1:
         # per-class device times of ONE extra step (HIP events around every C-ABI call, recorded on the stream the call is
         # launched on: the weight gradients run on the side stream); the dominant class's average is what the committed

@@ -83,7 +83,11 @@ class AsyncCheckpointWriter:
                 return host
             return obj.detach().clone()
         if isinstance(obj, dict):
-            return type(obj)((k, self._snapshot(v)) for k, v in obj.items())
+            out = type(obj)((k, self._snapshot(v)) for k, v in obj.items())
+            meta = getattr(obj, "_metadata", None)      # nn.Module.state_dict()'s per-module version table: the saved
+            if meta is not None:                        # ckpt_N.pt then loads exactly like the reference's (train.py:141)
+                out._metadata = meta
+            return out
         if isinstance(obj, (list, tuple)):
             return type(obj)(self._snapshot(v) for v in obj)
         return obj

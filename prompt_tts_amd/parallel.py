@@ -28,6 +28,12 @@ class GradReducer:
         # wait for the weight-gradient side stream and fold the replicated small gradients, so backward never stalls
         self.pre_flush = None
         self.joins_side_stream = False
+        # timing=True (bench.py, one instrumented step): HIP events on the COMMUNICATION stream around every bucket and one on
+        # the compute stream where backward ends; timing_ms() then says how long the collectives ran and how much of that the
+        # compute stream had to wait for
+        self.timing = False
+        self._ev = []
+        self._ev_bwd_end = None
 
     @property
     def grad_scale(self):
@@ -35,6 +41,19 @@ class GradReducer:
 
     def begin(self):
         self._pending, self._pending_bytes, self._done, self._work, self.launched = [], 0, [], [], []
+        self._ev, self._ev_bwd_end = [], None
+
+    def timing_ms(self):
+        """After a step run with timing=True and a device synchronize: {"allreduce_ms": time the comm stream spent inside the
+        buckets' collectives, "exposed_ms": how long after the end of backward the last collective finished (what the optimizer
+        waits for), "overlap_pct": share of the collective time hidden under backward, "buckets", "bytes"}."""
+        if not self._ev:
+            return None
+        busy = sum(e0.elapsed_time(e1) for e0, e1, _ in self._ev)
+        exposed = max(0.0, self._ev_bwd_end.elapsed_time(self._ev[-1][1])) if self._ev_bwd_end is not None else busy
+        return {"allreduce_ms": busy, "exposed_ms": min(exposed, busy), "buckets": len(self._ev),
+                "overlap_pct": 100.0 * (1.0 - min(exposed, busy) / busy) if busy > 0 else 0.0,
+                "bytes": sum(b for _, _, b in self._ev)}
 
     def on_ready(self, module):
         if self.world == 1:
@@ -67,8 +86,13 @@ class GradReducer:
             with torch.cuda.stream(self.stream):
                 if self.pre_flush is not None:
                     self.pre_flush()
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self.stream)
                 for lo, hi in ranges:
                     dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self.stream)
+                    self._ev.append((e0, e1, sum(4 * (hi - lo) for lo, hi in ranges)))
         else:
             for lo, hi in ranges:
                 self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -87,6 +111,8 @@ class GradReducer:
         if pos < self.flat.numel():
             rest.append((pos, self.flat.numel()))
         self._pending += rest
+        if self.cuda and self.timing:
+            self._ev_bwd_end = torch.cuda.Event(enable_timing=True); self._ev_bwd_end.record(torch.cuda.current_stream())
         self._flush()
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)

@@ -3,6 +3,7 @@
 
   accelerate launch train.py --data_file d.tar --log_dir logs --config_file 1d_config.json --ckpt_dir ckpt/
   python -m torch.distributed.run --nproc-per-node 8 train.py ...        (same thing; one process per GPU)
+  python train.py --gpus 8 ...                                           (same thing; starts its own ranks)
   python train.py --synthetic 256 --config_file ... --log_dir ... --ckpt_dir ...   (no tar needed)
 
 Differences from the reference, all behind the same surface: the step is the fused HIP path
@@ -20,7 +21,7 @@ import os
 
 import torch
 
-from prompt_tts_amd import checkpoint, parallel
+from prompt_tts_amd import checkpoint, launch, parallel
 from prompt_tts_amd.tts.dataloader import DeviceFeeder, SyntheticDataset, create_dataloader
 from prompt_tts_amd.tts.models import TTSSingleSpeaker
 
@@ -47,12 +48,12 @@ def lr_lambda(name, num_warmup_steps, num_training_steps):
 def main(args):
     config = json.load(open(args.config_file, "r"))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("PT_TRAIN_BACKEND", "nccl")                 # "gloo": rehearse the N-rank path on one GPU
+    local = launch.local_device_index(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PT_TRAIN_BACKEND", "nccl")             # "gloo": rehearse the N-rank path on one GPU
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
@@ -166,6 +167,8 @@ def parse_args():
     p.add_argument("--num_workers", type=int, default=0, help="DataLoader worker processes (collate off the step loop)")
     p.add_argument("--prefetch", type=int, default=1, help="1: pin + copy batches to the GPU two steps ahead (DeviceFeeder)")
     p.add_argument("--resume_epoch", type=int, default=0, help="continue after this epoch from ckpt_dir's ckpt_N.pt / optim_N.pt")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="N > 1 without a launcher: start N ranks (one per GPU) the way `accelerate launch` does for the reference")
     a = p.parse_args()
     if not a.synthetic and not a.data_file:
         p.error("--data_file is required (or --synthetic N)")
@@ -173,4 +176,7 @@ def parse_args():
 
 
 if __name__ == "__main__":
-    main(parse_args())
+    _args = parse_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # fresh children, started before this process touches the GPU
+        raise SystemExit(launch.spawn_ranks(_args.gpus, os.path.abspath(__file__), __import__("sys").argv[1:]))
+    main(_args)
