@@ -11,7 +11,9 @@
  *     weight shadows: PT_F32 (parity mode, exact-f32 MFMA) or PT_BF16 (bf16 MFMA, f32 accumulate);
  *   - statistics, biases, LSE, losses, master weights and ALL weight gradients are f32;
  *   - return value 0 = launched; <0 = refused before any launch (see pt_status); never throws.
- *   - re-entrant and thread-safe: no global mutable state.
+ *   - re-entrant and thread-safe.  Process-wide state is limited to: diagnostic switches read from the environment once
+ *     (thread-safe function-local statics; the defaults are the product), and the per-THREAD word behind
+ *     pt_last_hip_error().  Nothing else outlives a call.
  */
 #ifndef PROMPT_TTS_HIP_H
 #define PROMPT_TTS_HIP_H
@@ -327,12 +329,22 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *   xg0   [B*T][4H]  = x W_ih0^T + b_ih0 + b_hh0  (computed by the caller with pt_gemm)
  *   layer 1 uses wcat1 [4H][2H] = [W_ih1 | W_hh1] and bias1 [4H] = b_ih1 + b_hh1
  *   out_elu[(b,t)][:] = ELU(h1_t + x[(b,t)][:])
- * h0_seq, h1_seq [B*T][H] and c0, c1 [B][H] (f32) are caller-provided scratch.  The library issues T+1 dependent
- * launches (layer 0 step s beside layer 1 step s-1); latency-bound: reports steps/s, not a roofline fraction. */
+ * h0_seq, h1_seq [B*T][H] and c0, c1 [B][H] (f32) are caller-provided scratch.  Two forms, chosen by the library:
+ *   - persistent (PT_BF16, H = 512, B*T*H*2 >= 256 KiB + 256, a device with >= 64 CUs): ONE launch per 16 * min(4, CUs / 64)
+ *     batch rows runs all T steps with the recurrent weights resident in LDS; clusters of 64 workgroups (one per CU) exchange
+ *     the new hidden vectors every step through data-tagged 8-byte granules in h0_seq (its first 256 bytes hold the status
+ *     word).  Every workgroup of a launch must be resident at once; every wait is bounded;
+ *   - per step (PT_F32, other H, small devices, PT_LSTM_PERSIST=0): T + 1 dependent launches (layer 0 step s beside layer 1
+ *     step s - 1).
+ * `status`: device pointer to ONE 32-bit word owned by the caller, or NULL.  The call clears it on the stream; after the call
+ * has completed on the stream, 0 = ok and non-zero = a hand-off of the persistent form timed out (out_elu is then INVALID:
+ * copy the word back -- e.g. to pinned memory on the same stream -- and check it before using the result).  With NULL the word is
+ * the first 32 bits of h0_seq.  Latency-bound: reports steps/s, not a roofline fraction. */
 typedef struct pt_lstm2_desc {
   int64_t B, T, H;
   const void* x; const void* xg0; const void* whh0; const void* wcat1; const float* bias1;
   void* h0_seq; void* h1_seq; float* c0; float* c1; void* out_elu;
+  void* status;
 } pt_lstm2_desc;
 int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/prompt_tts_hip.h"
 
 #define PT_WAVE 64
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gelu_erf_fast(float x, float& gelu, float& dgelu
 }
 
 // host-side launch check
-extern "C" int pt_g_last_hip_error;      // capi.hip: the hipError_t behind the most recent PT_ERR_LAUNCH (diagnostics)
+extern thread_local int pt_g_last_hip_error;      // capi.hip: the hipError_t behind this thread's most recent PT_ERR_LAUNCH (diagnostics)
 #define PT_LAUNCH_CHECK()                                  \
   do {                                                     \
     const hipError_t pt_e_ = hipGetLastError();            \
@@ -138,5 +139,12 @@ extern "C" int pt_g_last_hip_error;      // capi.hip: the hipError_t behind the 
       return PT_ERR_LAUNCH;                                \
     }                                                      \
   } while (0)
+
+// Diagnostic switches are read from the environment ONCE per process: a function-local `static const int` is initialised
+// under the C++11 thread-safe-statics guarantee, so concurrent first calls do not race.
+static inline int pt_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 static inline bool pt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -282,7 +282,9 @@ struct LstmPersist {
   const bf16_t* x; const bf16_t* xg0; const bf16_t* whh0; const bf16_t* wcat1; const float* bias1;
   bf16_t* out_elu;
   unsigned long long* gx;   // granules [2 parity][2 layer][clusters * 16 rows][256 unit pairs]; zeroed by the launch function
-  unsigned* err;            // error word; zeroed by the launch function
+  unsigned* err;            // status word (pt_lstm2_desc.status or the first word of the workspace); zeroed once per CALL
+  int spin_limit;           // poll rounds before a hand-off counts as lost (2^20 ~ a second; tests shrink it)
+  int fault_slice;          // >= 0: that workgroup publishes wrong tags (test hook: forces the timeout path); -1 in production
 };
 
 __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist p) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
           }
           break;
         }
-        if (++spin > (1 << 20) || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           if (lane == 0) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abort_flag = 1; }
           break;
         }
@@ -430,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
       const unsigned mine = (unsigned)f32_to_bf16_bits(hn);
       const unsigned other = (unsigned)__shfl_down((int)mine, 1, 64);
       if ((jj & 1) == 0) {
-        const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | (unsigned long long)(mine | (other << 16));
+        const unsigned tag = (unsigned)(s + 1) + ((int)blockIdx.x == p.fault_slice ? 0x40000000u : 0u);
+        const unsigned long long gran = ((unsigned long long)tag << 32) | (unsigned long long)(mine | (other << 16));
         unsigned long long* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + 16 * c + b)) * 256 + (LP_UNITS * u + jj) / 2;
         __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -916,23 +919,39 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   p.x = (const char*)d->x; p.xg0 = (const char*)d->xg0; p.whh0 = (const char*)d->whh0; p.wcat1 = (const char*)d->wcat1;
   p.bias1 = d->bias1; p.h0_seq = (char*)d->h0_seq; p.h1_seq = (char*)d->h1_seq; p.c0 = d->c0; p.c1 = d->c1; p.out_elu = (char*)d->out_elu;
   hipStream_t s = (hipStream_t)stream;
-  // persistent form (bf16, H = 512): the recurrence in one launch per <= 64 batch rows, weights resident in LDS; h0_seq is its
-  // exchange workspace (hidden vectors of the current / previous tick + arrival counters), h1_seq / c0 / c1 stay unused
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("PT_LSTM_PERSIST"); persist = e ? atoi(e) : 1; }
-  const int64_t ws_need = 256 + 2ll * 2 * 64 * 256 * 8;           // error word + granules of 4 clusters
-  if (persist && dtype == PT_BF16 && d->H == LP_H && d->B * d->T * d->H * 2 >= ws_need) {
-    for (int64_t b0 = 0; b0 < d->B; b0 += 64) {
+  // persistent form (bf16, H = 512): the recurrence in one launch per <= 16 * clusters batch rows, weights resident in LDS;
+  // h0_seq is its exchange workspace (status word + data-tagged granules), h1_seq / c0 / c1 stay unused.  The cluster's 64
+  // workgroups spin on each other, so every workgroup of a launch must be resident at once: one per CU (112 KiB of LDS), i.e.
+  // clusters <= CUs / 64 -- a partitioned (CPX), CU-masked or smaller device gets fewer clusters per launch, or the per-step
+  // kernels.  A lost hand-off (e.g. another stream's LDS-heavy kernels holding CUs for longer than the spin bound) ends the
+  // launch early with the status word set: pt_lstm2_desc.status, which the caller must read before it trusts out_elu.
+  static const int persist = pt_env_int("PT_LSTM_PERSIST", 1);
+  unsigned* status = d->status ? reinterpret_cast<unsigned*>(d->status) : reinterpret_cast<unsigned*>(d->h0_seq);
+  if (d->status && hipMemsetAsync(d->status, 0, 4, s) != hipSuccess) return PT_ERR_LAUNCH;
+  int cus = 0, device = 0;
+  if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+  const int max_clusters = cus / LP_SLICES < 4 ? cus / LP_SLICES : 4;
+  const int64_t ws_need = 256 + 2ll * 2 * 64 * 256 * 8;           // status word + granules of 4 clusters
+  if (persist && max_clusters >= 1 && dtype == PT_BF16 && d->H == LP_H && d->B * d->T * d->H * 2 >= ws_need) {
+    // test hooks, read per call (never cached): a short spin bound and a workgroup that publishes wrong tags
+    const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
+    const int rows_per_launch = 16 * max_clusters;
+    for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
       LstmPersist q;
       q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
-      const int64_t nb = d->B - b0 < 64 ? d->B - b0 : 64;
+      const int64_t nb = d->B - b0 < rows_per_launch ? d->B - b0 : rows_per_launch;
       q.clusters = (int)((nb + 15) / 16);
       q.x = (const bf16_t*)d->x; q.xg0 = (const bf16_t*)d->xg0; q.whh0 = (const bf16_t*)d->whh0; q.wcat1 = (const bf16_t*)d->wcat1;
       q.bias1 = d->bias1; q.out_elu = (bf16_t*)d->out_elu;
-      q.err = reinterpret_cast<unsigned*>(d->h0_seq);
+      q.err = status;
       q.gx = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d->h0_seq) + 256);
-      // tags of an earlier call must not read as current: the granule block (and the error word) is cleared every launch
-      if (hipMemsetAsync(d->h0_seq, 0, (size_t)(256 + 2ll * 2 * q.clusters * 16 * 256 * 8), s) != hipSuccess) return PT_ERR_LAUNCH;
+      q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
+      q.fault_slice = e_fault ? atoi(e_fault) : -1;
+      // tags of an earlier launch must not read as current: the granule block is cleared every launch; the status word only
+      // once per call, so that a timeout in any launch of the call stays visible (later launches then bail out at once)
+      const bool first = b0 == 0;
+      char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
+      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 8), s) != hipSuccess) return PT_ERR_LAUNCH;
       hipLaunchKernelGGL(lstm2_persist_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
       PT_LAUNCH_CHECK();
     }

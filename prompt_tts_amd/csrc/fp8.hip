@@ -62,9 +62,14 @@ template <int FMT> __device__ __forceinline__ void scales(float* state, float& s
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   __syncthreads();
-  const float amax = __uint_as_float(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+  const uint32_t abits = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+  const float amax = __uint_as_float(abits);
   scale = amax > 0.f ? amax / FM : 1.f;
   inv = amax > 0.f ? FM / amax : 1.f;
+  // a tensor that holds an Inf or a NaN (its |bits| >= 0x7f80 win the integer maximum) must not come back as finite garbage:
+  // the published scale is NaN, so the GEMM's dequantisation (accumulator * scale_a * scale_b) poisons every output it feeds and
+  // the divergence reaches the loss / gradient norm as it does on the bf16 path
+  if (abits >= 0x7f800000u) { scale = __uint_as_float(0x7fc00000u); inv = 0.f; }
   if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = amax; state[1] = scale; }
 }
 __device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }

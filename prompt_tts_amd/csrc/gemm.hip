@@ -1252,10 +1252,8 @@ int launch_cfg(GemmParams p, hipStream_t s) {
 // configuration for A/B probing (tools/gemm_probe.py); PT_GEMM_8P_MASK selects which GEMM classes may use the eight-phase
 // kernel (bit 0 forward plain, 1 dgrad plain, 2 conv forward, 3 conv dgrad, 4 wgrad).
 inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
-  static int forced = -1, mask = -1, min8pk = -1;
-  if (forced < 0) { const char* e = getenv("PT_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-  if (mask < 0) { const char* e = getenv("PT_GEMM_8P_MASK"); mask = e ? atoi(e) : 0x0f; }
-  if (min8pk < 0) { const char* e = getenv("PT_GEMM_8P_MIN_K"); min8pk = e ? atoi(e) : 1536; }
+  static const int forced = pt_env_int("PT_GEMM_TILE", 0), mask = pt_env_int("PT_GEMM_8P_MASK", 0x0f),
+                   min8pk = pt_env_int("PT_GEMM_8P_MIN_K", 1536);
   if (forced == 128 || forced == 256 || forced == 512 || forced == 8) return forced;
   const int64_t tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.split_k;
   if (bf16 && ((mask >> cls) & 1) && tiles256 >= 192) return p.K >= min8pk ? 8 : 512;
@@ -1352,7 +1350,7 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
   p.tiles_m = p.tiles_n = 0;   // set per tile configuration at launch
   p.geglu_rows = d->geglu_rows;
   p.scale_a = p.scale_b = nullptr;
-  { static int nt = -1; if (nt < 0) { const char* e = getenv("PT_GEMM_NT"); nt = e ? atoi(e) : 0; } p.nt_store = nt; }
+  { static const int nt = pt_env_int("PT_GEMM_NT", 0); p.nt_store = nt; }
   if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
   if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
   if (d->act >= 2) {
@@ -1391,8 +1389,7 @@ extern "C" int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* sca
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, 1);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // short reductions (K < PT_GEMM_F8_8P_MIN_K bytes, default 3072 = 24 k-tiles) on the two-stage 256 x 256 kernel, like bf16
-  static int min8pk = -1;
-  if (min8pk < 0) { const char* e = getenv("PT_GEMM_F8_8P_MIN_K"); min8pk = e ? atoi(e) : 3072; }
+  static const int min8pk = pt_env_int("PT_GEMM_F8_8P_MIN_K", 3072);
   if (p.K < min8pk) {
     constexpr int NT256 = TileCfg<256, 256>::NTHREADS;
     if (a_format == PT_FP8_E4M3) hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, false, 0, 0, 256, 256, 1>), grid, dim3(NT256), 0, s, p);

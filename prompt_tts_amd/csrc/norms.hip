@@ -627,8 +627,7 @@ __global__ __launch_bounds__(64 * CCH) void gn_slab_bwd_kernel(const GnSlab p) {
 
 // slab width in 16-byte chunks (4: 32 channels / 256 threads, 8: 64 channels / 512 threads), or 0: use the two-pass kernels
 inline int gn_slab_cch(int64_t N, int64_t C1, int64_t C2, int64_t G) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("PT_GN_SLAB"); enabled = e ? atoi(e) : 1; }
+  static const int enabled = pt_env_int("PT_GN_SLAB", 1);
   const int64_t C = C1 + C2;
   if (!enabled || G <= 0 || C % G != 0 || N < 1 || N > 2048) return 0;
   const int64_t cpg = C / G;

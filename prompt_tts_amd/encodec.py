@@ -3,7 +3,8 @@
 Token-major activations; the transposed convs are plain GEMMs whose N = r*Cout output columns ARE the r new
 time steps (zero-copy upsampling), the residual block's 1x1 conv and 1x1 shortcut are fused into one concat-K
 GEMM, ELUs live in epilogues (or on fragment load), the 24 kHz end (<= 64 channels) runs on the row-streaming
-kernel, the LSTM recurrence on T+1 dependent launches issued from inside the library.
+kernel or the fused stage kernels, the LSTM recurrence as ONE persistent launch (bf16) or T+1 dependent launches (f32)
+issued from inside the library; its status word is checked before a waveform is returned (LstmStatus).
 Weights are a flat dict of EFFECTIVE tensors (weight-norm folded at load time; names in `WEIGHT_KEYS`).
 """
 import ctypes as C
@@ -62,6 +63,49 @@ def _pad_cols(m, mult):
     return out
 
 
+class LstmStatus:
+    """The status word of pt_lstm2_forward (include/prompt_tts_hip.h): cleared by the call, set by the persistent kernel when a
+    hand-off between its workgroups timed out (not all of them resident, e.g. another stream's kernels holding CUs) -- the
+    output is then garbage.  The word is copied to pinned host memory ON THE STREAM right behind the LSTM, so the rest of the
+    decoder is enqueued without a stall; check() waits for that copy only and raises instead of returning a wrong waveform."""
+
+    def __init__(self, device):
+        self.dev_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+
+    def ptr(self):
+        return self.dev_word.data_ptr()
+
+    def fetch(self):
+        self.host_word.copy_(self.dev_word, non_blocking=True)
+        self.event.record(torch.cuda.current_stream(self.dev_word.device))
+
+    def check(self):
+        self.event.synchronize()
+        if int(self.host_word[0]) != 0:
+            raise RuntimeError("pt_lstm2_forward: a hand-off of the persistent LSTM timed out (its workgroups were not all "
+                               "resident: is another stream holding CUs?); the result was discarded -- retry, or set "
+                               "PT_LSTM_PERSIST=0 for the per-step kernels")
+
+
+def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None):
+    """Two-layer LSTM + skip + ELU over (B*T, 512) token-major rows; returns (ELU(h1 + x), LstmStatus to check()).
+    `status`: a reusable LstmStatus (pinned allocation is slow); it must have been check()ed since its last use."""
+    M = B * T
+    h0 = torch.empty(M, 512, dtype=dtype, device=device); h1 = torch.empty_like(h0); ze = torch.empty_like(h0)
+    c0 = torch.empty(B, 512, dtype=torch.float32, device=device); c1 = torch.empty_like(c0)
+    st = status if status is not None else LstmStatus(device)
+    ld = L.pt_lstm2_desc()
+    ld.B, ld.T, ld.H = B, T, 512
+    ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = x.data_ptr(), xg0.data_ptr(), w_hh0.data_ptr(), wcat1.data_ptr(), bias1.data_ptr()
+    ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
+    ld.status = st.ptr()
+    check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
+    st.fetch()
+    return ze, st
+
+
 FUSED_TAIL = __import__("os").environ.get("PT_ENCODEC_FUSED_TAIL", "1") != "0"
 FUSED_STAGES = __import__("os").environ.get("PT_ENCODEC_FUSED_STAGES", "1") != "0"
 
@@ -103,6 +147,12 @@ class EncodecDecoder:
         self.wfin, self.bfin = d(_pad_cols(_conv_mat(W["final.w"]), 32)), f(W["final.b"])
 
     # -- helpers --------------------------------------------------------------------------------------------------
+    def _lstm_status(self):
+        st = getattr(self, "_lstm_st", None)
+        if st is None:
+            st = self._lstm_st = LstmStatus(self.device)
+        return st
+
     def _rowconv(self, Bn, n_rows, x, cin, taps, rowmap, w, bias, N, y, act=0, elu_x=0, x2=None, cin2=0, elu_x2=0, y_f32=False):
         d = L.pt_rowconv_desc()
         d.B, d.n_rows = Bn, n_rows
@@ -120,6 +170,11 @@ class EncodecDecoder:
     @torch.no_grad()
     def decode(self, codes):
         """codes (B, n_q, T) int64 in [0,1023] -> wav (B, 1, 320*T) f32."""
+        wav, lstm_status = self._decode(codes)
+        lstm_status.check()              # never hand out a waveform computed from a timed-out recurrence
+        return wav
+
+    def _decode(self, codes):
         if codes.dim() != 3:
             raise BaseException("The encoded_frames must have the shape of [B, N_q, T]")
         if codes.shape[1] != self.n_q:
@@ -136,13 +191,7 @@ class EncodecDecoder:
         ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0), y0, pt, bias=self.b0)
         xg0 = self._empty(M, 2048)
         ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
-        h0 = self._empty(M, 512); h1 = self._empty(M, 512); ze = self._empty(M, 512)
-        c0 = torch.empty(B, 512, dtype=torch.float32, device=self.device); c1 = torch.empty_like(c0)
-        ld = L.pt_lstm2_desc()
-        ld.B, ld.T, ld.H = B, T, 512
-        ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = y0.data_ptr(), xg0.data_ptr(), self.w_hh0.data_ptr(), self.wcat1.data_ptr(), self.bias1.data_ptr()
-        ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
-        check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
+        ze, lstm_status = run_lstm2(B, T, y0, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status())
         xe, n = ze, T                     # xe = ELU(stage input), n = rows per batch item
         fuse_tail = (self.dtype == torch.bfloat16 and FUSED_TAIL and
                      (self.stages[-1]["r"], self.stages[-1]["cin"], self.stages[-1]["cout"]) == (2, 64, 32) and n * 160 >= 8)
@@ -158,7 +207,7 @@ class EncodecDecoder:
                 td.wf, td.bf, td.wfin, td.bfin = st["wf"].data_ptr(), st["bf"].data_ptr(), self.wfin.data_ptr(), self.bfin.data_ptr()
                 td.wav = wav.data_ptr()
                 check(lib.pt_encodec_tail(C.byref(td), pt, ops._stream()), "pt_encodec_tail")
-                return wav.view(B, 1, n * r)
+                return wav.view(B, 1, n * r), lstm_status
             if self.dtype == torch.bfloat16 and FUSED_STAGES and (r, cin, cout) == (4, 128, 64) and n >= 4:
                 # transposed conv + residual block of the 3 kHz -> 12 kHz stage in one launch
                 oute = self._empty(B * n * r, cout)
@@ -206,7 +255,7 @@ class EncodecDecoder:
             xe, n = oute, n_out
         wav = torch.empty(B * n, 1, dtype=torch.float32, device=self.device)
         self._rowconv(B, n, xe, 32, 7, L.PT_MAP_CAUSAL_REFLECT, self.wfin, self.bfin, 1, wav, y_f32=True)
-        return wav.view(B, 1, n)
+        return wav.view(B, 1, n), lstm_status
 
 
 # =====================================================================================================================
@@ -283,6 +332,7 @@ class EncodecEncoder:
         self.wfin, self.bfin = d(_conv_mat(W["enc.final.w"])), f(W["enc.final.b"])
 
     _rowconv = EncodecDecoder._rowconv
+    _lstm_status = EncodecDecoder._lstm_status
     _empty = EncodecDecoder._empty
 
     def _rowconv_strided(self, Bn, n_out, x, cin, taps, stride, w, bias, N, y):
@@ -335,16 +385,11 @@ class EncodecEncoder:
         M = B * T
         xg0 = self._empty(M, 2048)
         ops.gemm(M, 2048, 512, ops.plain(cur), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
-        h0 = self._empty(M, 512); h1 = self._empty(M, 512); ze = self._empty(M, 512)
-        c0 = torch.empty(B, 512, dtype=torch.float32, device=self.device); c1 = torch.empty_like(c0)
-        ld = L.pt_lstm2_desc()
-        ld.B, ld.T, ld.H = B, T, 512
-        ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = cur.data_ptr(), xg0.data_ptr(), self.w_hh0.data_ptr(), self.wcat1.data_ptr(), self.bias1.data_ptr()
-        ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
-        check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
+        ze, lstm_status = run_lstm2(B, T, cur, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status())
         emb = torch.empty(M, 128, dtype=torch.float32, device=self.device)
         ops.gemm(M, 128, 7 * 512, ops.conv(ze, 512, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.wfin), emb, pt,
                  bias=self.bfin, out_kind=L.PT_OUT_F32 if self.dtype != torch.float32 else L.PT_OUT_T)
+        lstm_status.check()
         return emb, B, T
 
     @torch.no_grad()

@@ -49,6 +49,15 @@ def conv_dgrad_weight(w3, cout, cin_pad):
     return None
 
 
+def geglu_interleave_ok(F2, d):
+    """May the GEGLU projection weight [F2][d] keep its bf16 shadow rows interleaved (value / gate of a column in one lane's
+    accumulators: GEGLU in the ff1 epilogue)?  Its weight gradient can then only be un-interleaved by the fold of the GROUPED
+    weight-gradient launch, so the predicate is exactly what _queue_wgrad accepts for dW [F2][d]: both sides >= 128 and at most
+    WGRAD_GROUP_WGS tiles of 256 x 256 -- d = 64 or d >= 1536 (288 tiles) train with the plain layout + stand-alone GEGLU."""
+    return (GEGLU_FUSED and WGRAD_GROUPED and F2 % 512 == 0 and d % 8 == 0 and F2 >= 128 and d >= 128
+            and math.ceil(F2 / 256) * math.ceil(d / 256) <= WGRAD_GROUP_WGS)
+
+
 class ParamStore:
     """Flat storage for every parameter of `module` on `device`; `dtype` is the activation/shadow dtype."""
 
@@ -82,8 +91,8 @@ class ParamStore:
             frozen = name.endswith("proj_out.weight") or name.endswith("proj_out.bias")
             # GEGLU projection (diffusers FeedForward.net[0].proj, [2F][d]): in bf16 its shadow rows are interleaved so the ff1
             # GEMM epilogue can apply value * gelu(gate) in registers (csrc/gemm.hip act 2 / 3)
-            geglu = (GEGLU_FUSED and dtype == torch.bfloat16 and name.endswith("ff.net.0.proj.weight") and p.dim() == 2
-                     and p.shape[0] % 512 == 0 and p.shape[1] % 8 == 0)
+            geglu = (dtype == torch.bfloat16 and name.endswith("ff.net.0.proj.weight") and p.dim() == 2
+                     and geglu_interleave_ok(p.shape[0], p.shape[1]))
             if geglu:
                 self.geglu_ids.add(id(p))
             if is_conv3:
@@ -358,8 +367,15 @@ _side = {}
 _DIAG_SKIP_WGRAD = __import__("os").environ.get("PT_DIAG_SKIP_WGRAD", "0") == "1"
 
 
-N_SIDE = int(__import__("os").environ.get("PT_SIDE_STREAMS", "1"))     # wgrad launches rotate over this many side streams
+N_SIDE = int(__import__("os").environ.get("PT_SIDE_STREAMS", "1"))     # single-launch wgrads rotate over this many side streams
 _side_rr = [0]
+
+
+def _side_stream0(device):
+    st = _side.get((device, 0))
+    if st is None:
+        st = _side[(device, 0)] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _side_stream(device):
@@ -388,15 +404,18 @@ def main_stream(device):
     return st
 
 
-def on_side_stream(fn, *tensors):
-    """Run fn() (kernel launches reading `tensors`) on the wgrad side stream, ordered after the current stream."""
+def on_side_stream(fn, *tensors, ordered=False):
+    """Run fn() (kernel launches reading `tensors`) on the wgrad side stream, ordered after the current stream.
+    ordered=True: always the SAME side stream (stream 0) -- the grouped weight-gradient launches share one slab workspace,
+    their folds add into the gradients with plain read-modify-writes and deferred boundary corrections must land after their
+    conv, so consecutive groups need strict stream order whatever PT_SIDE_STREAMS says."""
     if _DIAG_SKIP_WGRAD:                 # timing diagnostic only (wrong gradients): the main-stream chain by itself
         return
     if not WGRAD_SIDE_STREAM:
         fn()
         return
     dev = tensors[0].device
-    side = _side_stream(dev)
+    side = _side_stream0(dev) if ordered else _side_stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         fn()
@@ -507,7 +526,7 @@ class _WgradQueue:
                     self.lists[c] = []
                     descs = [d for d, _, _ in lst]
                     tensors = [t for _, _, ts in lst for t in ts]
-                    on_side_stream(lambda: ops.wgrad_group(descs, self.ws, WGRAD_GROUP_WGS), *tensors)
+                    on_side_stream(lambda: ops.wgrad_group(descs, self.ws, WGRAD_GROUP_WGS), *tensors, ordered=True)
                 pending, self.deferred[c] = self.deferred[c], []
                 for item in pending:           # their conflicting partners have been launched: ordinary members from here on
                     self.add(c, *item)

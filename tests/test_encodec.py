@@ -328,3 +328,40 @@ def test_hip_encoder_bf16_embeddings(dev):
     want = oe.encoder_embeddings(wav, W)
     err = float((emb.view(B, T, 128).permute(0, 2, 1).cpu() - want).abs().max() / want.abs().max())
     assert err < 8e-2, err
+
+
+@pytest.mark.gpu
+def test_persistent_lstm_timeout_raises_instead_of_returning_garbage(dev, monkeypatch):
+    """VERDICT r02 / ADVICE r02: a lost hand-off of the persistent LSTM (its workgroups not all resident) used to return a garbage
+    waveform with PT_OK.  Force the timeout branch -- workgroup 5 publishes wrong tags, the spin bound is shrunk so that the
+    launch gives up after a few milliseconds -- and require decode() to RAISE; then decode again without the fault: the status
+    word is cleared per call and the result is the good one."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    W = oe.random_weights(5)
+    dec = EncodecDecoder(W, device=dev, dtype=torch.bfloat16)
+    codes = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(3)).to(dev)   # 2 clusters, persistent form
+    good = dec.decode(codes).cpu()
+    monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
+    monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "5")
+    with pytest.raises(RuntimeError, match="timed out"):
+        dec.decode(codes)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("PT_LSTM_DEBUG_SPIN"); monkeypatch.delenv("PT_LSTM_DEBUG_FAULT_SLICE")
+    again = dec.decode(codes).cpu()
+    assert torch.equal(again, good)
+
+
+@pytest.mark.gpu
+def test_persistent_lstm_timeout_in_a_later_launch_of_the_call_is_sticky(dev, monkeypatch):
+    """70 rows = two launches (4 clusters + 1): the fault sits in workgroup 70, which exists only in the FIRST launch; the second
+    launch must not clear the word."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    dec = EncodecDecoder(oe.random_weights(5), device=dev, dtype=torch.bfloat16)
+    codes = torch.randint(0, 1024, (70, 8, 40), generator=torch.Generator().manual_seed(4)).to(dev)
+    monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
+    monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "70")
+    with pytest.raises(RuntimeError, match="timed out"):
+        dec.decode(codes)
+    torch.cuda.synchronize()

@@ -94,3 +94,22 @@ def test_fp8_entry_points_refuse_bad_arguments(dev):
     a8 = torch.zeros(256, 128, dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError):                                    # K % 16 != 0
         ops.gemm_fp8(256, 256, 120, a8, a8, torch.empty(256, 256, dtype=torch.bfloat16, device=dev), torch.ones(258, device=dev), torch.ones(258, device=dev))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), float("-inf")])
+def test_fp8_quantiser_propagates_non_finite_values(dev, bad):
+    """one NaN / Inf element used to come back as a finite clamp value (-448 / 0), so a diverged activation re-entered
+    the fp8 GEMMs as finite garbage.  Now the published scale is NaN and the GEMM output is poisoned, as on the bf16 path."""
+    from prompt_tts_amd import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 256, 256, 128
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    a[17, 5] = bad
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    a8 = torch.empty(M, K, dtype=torch.uint8, device=dev); w8 = torch.empty(N, K, dtype=torch.uint8, device=dev)
+    sa = torch.empty(258, device=dev); sw = torch.empty(258, device=dev)
+    ops.fp8_quantize(a, a8, sa, 0); ops.fp8_quantize(w, w8, sw, 0)
+    assert torch.isnan(sa[1]) and torch.isfinite(sw[1])
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm_fp8(M, N, K, a8, w8, out, sa, sw)
+    assert torch.isnan(out.float()).all()
