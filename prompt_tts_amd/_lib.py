@@ -12,7 +12,8 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: the PyTorch-ROCm whe
 #               launch here fails with "no ROCm-capable device is detected".
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprompt_tts_hip.so")
+# PT_TTS_LIB: another build of the SAME library (tests load the host-sanitizer build, csrc `make asan`, this way)
+LIB_PATH = os.environ.get("PT_TTS_LIB") or os.path.join(_HERE, "libprompt_tts_hip.so")
 
 PT_F32, PT_BF16 = 0, 1
 PT_FP8_E4M3, PT_FP8_E5M2 = 0, 1

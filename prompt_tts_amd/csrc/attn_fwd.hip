@@ -165,12 +165,16 @@ template <typename T, int D> int launch_fwd(const AttnParams& p, hipStream_t s) 
 }  // namespace
 
 int pt_attn_fill_params(const pt_attn_desc* d, int dtype, bool bwd, AttnParams& p);   // attn_bwd.hip
+int pt_attn2_fwd(const AttnParams& p, int D, hipStream_t s);                           // attn2_fwd.hip
 
 extern "C" int pt_attn_fwd(const pt_attn_desc* d, int dtype, pt_stream stream) {
   AttnParams p;
   int st = pt_attn_fill_params(d, dtype, false, p);
   if (st) return st;
   hipStream_t s = (hipStream_t)stream;
+  // bf16: the second-generation kernel (32x32x16 MFMA, LDS-DMA staging, lazy maximum); PT_ATTN_V2=0 keeps the round-2 kernel
+  static const int v2 = pt_env_int("PT_ATTN_V2", 1);
+  if (dtype == PT_BF16 && v2) return pt_attn2_fwd(p, (int)d->D, s);
 #define FWD(TT) \
   switch (d->D) { case 32: return launch_fwd<TT, 32>(p, s); case 64: return launch_fwd<TT, 64>(p, s); \
                   case 128: return launch_fwd<TT, 128>(p, s); default: return PT_ERR_SHAPE; }

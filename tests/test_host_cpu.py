@@ -297,9 +297,9 @@ def test_wgrad_queue_deferred_problems_never_share_a_launch_with_their_partner(m
     and the final flush drains everything."""
     import torch
     from prompt_tts_amd import engine as E
-    launches = []
+    launches, ordered_calls = [], []
     monkeypatch.setattr(E.ops, "wgrad_group", lambda descs, ws, wgs: launches.append(list(descs)))
-    monkeypatch.setattr(E, "on_side_stream", lambda fn, *tensors: fn())
+    monkeypatch.setattr(E, "on_side_stream", lambda fn, *tensors, ordered=False: (ordered_calls.append(ordered), fn())[1])
     monkeypatch.setattr(E.ops, "wgrad_group_ws_floats", lambda wgs: 16)
     q = E._WgradQueue(torch.device("cpu"))
     for conv in range(7):                                 # 7 convs: main problem + two deferred corrections each
@@ -315,6 +315,9 @@ def test_wgrad_queue_deferred_problems_never_share_a_launch_with_their_partner(m
     for i in range(7):
         assert where[f"c{i}a"] > where[f"main{i}"] and where[f"c{i}b"] > where[f"main{i}"]     # strictly later launches
     assert not q.lists[0] and not q.lists[1] and not q.deferred[0] and not q.deferred[1]
+    # every group asks for the ONE ordered side stream (shared slab workspace, read-modify-write folds): PT_SIDE_STREAMS > 1
+    # must not let two groups overlap
+    assert ordered_calls and all(ordered_calls)
 
 
 def test_importing_the_package_first_loads_one_hip_runtime():

@@ -14,7 +14,8 @@ from prompt_tts_amd.encodec import EncodecDecoder   # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=torch.bfloat16)
+    dtype = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else torch.bfloat16
+    dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=dtype)
     codes = torch.randint(0, 1024, (64, 8, 1024), generator=torch.Generator().manual_seed(7)).to(dev)
     for _ in range(2):
         dec.decode(codes)
@@ -52,6 +53,13 @@ def main():
         dec.decode(codes)
     e1.record(); torch.cuda.synchronize()
     print(f"decode 64 x 1024: {e0.elapsed_time(e1) / 5:.3f} ms per batch")
+    import time
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        wav, st = dec._decode(codes); t1 = time.perf_counter()
+        st.event.synchronize(); t2 = time.perf_counter()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        print(f"  host: enqueue {1e3 * (t1 - t0):.2f} ms, LSTM status event +{1e3 * (t2 - t1):.2f} ms, rest of the stack +{1e3 * (t3 - t2):.2f} ms")
 
 
 if __name__ == "__main__":
