@@ -168,6 +168,14 @@ def decode_cpu_baseline(budget_s=15.0):
             "sample": f"{reps} decode(s) of {Bc} x {Tc} frames with the CPU oracle (f32, {dt:.2f} s each; the LSTM is sequential in T)"}
 
 
+def decode_traffic():
+    path = os.path.join(ROOT, "profiles", "r03_decode_pmc.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("decode_bytes")
+
+
 def decode_parity(dev, B=2, T=1024):
     """Error of the HIP decoder in both dtypes against the CPU oracle on the SAME codes and weights (max |error| / waveform peak;
     north_star: 1e-3 relative for floating point).  f32 = the reference's own precision (decode_codec.py:12-16 decodes in fp32)."""
@@ -254,7 +262,16 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
     out = {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
            "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
            "lstm_ms": lstm_ms, "lstm_steps_per_s": 2 * T / (lstm_ms * 1e-3) if lstm_ms else None,
-           "achieved_tflops": flops / (ms * 1e-3) / 1e12, "roofline": hbm,
+           "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+           # the decode is compute / latency bound (19.9 M MAC per frame against 1.3 KB of algorithmic I/O per frame): priced
+           # against the dense bf16 MFMA peak; the launch-boundary HBM view of the conv stack stays as `hbm_view`
+           "roofline": {"bound": "mfma", "kernel": "whole decode (RVQ gather, conv stack, persistent LSTM, fused stages)",
+                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], "traffic": decode_traffic(),
+                        "algorithmic_bytes_per_batch": (8 * 8 + 320 * 4) * prompts * T + 34_000_000,
+                        "note": "traffic = HBM-side bytes of one decode from the committed PMC passes (profiles/r03_decode_pmc.json), "
+                                "null if absent; algorithmic I/O = codes in + waveform out + weights once"},
+           "hbm_view": hbm,
            "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
            "weights": "seeded random (no checkpoint offline)"}
@@ -319,8 +336,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the Encodec decode leg (audio-s/s)")
     ap.add_argument("--kernel-timing", action="store_true", help="per-symbol HIP-event timing of one extra step")
+    ap.add_argument("--only-decode", action="store_true", help="only the Encodec decode leg (configs[3]); for the decode PMC passes")
     args = ap.parse_args()
 
+    if args.only_decode:
+        torch.cuda.set_device(0)
+        out = decode_bench(torch.device("cuda", 0), cpu=not args.no_cpu_baseline)
+        print(json.dumps(dict(out, n_gpus=1, higher_is_better=True, data="synthetic", config={"workload": "BASELINE configs[3]: Encodec 24 kHz "
+                              "decode of 64 prompts x 1024 frames"})), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one command, N ranks (the reference is launched once and fans out: train.py:25-29, README.md:36-42).  The children are
         # FRESH processes started before this one has made any torch.cuda / HIP call; this process never touches the GPU.

@@ -273,7 +273,7 @@ int pt_sumsq(const float* g, float* out, int64_t n, pt_stream stream);
  * clip = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) read on device; p -= lr*wd*p; m,v update; p -= step.
  * Also refreshes the activation-dtype weight shadow.  seg = table of n_seg tensors (pt_param_seg).
  * Gradients of layout-1 (Conv1d k=3) tensors are stored [Cout][3][Cin] (what the wgrad GEMM writes with contiguous
- * atomics); p, m, v keep the reference (Cout, Cin, 3) order. */
+ * atomics) and the Adam moments m, v are indexed like the gradient; only p keeps the reference (Cout, Cin, 3) order. */
 typedef struct pt_param_seg {
   int64_t offset;        /* element offset in the flat master / grad / m / v buffers            */
   int64_t numel;
@@ -289,6 +289,18 @@ int pt_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, co
                   int64_t n_seg, int64_t n_total, const float* gnorm_sq, float max_norm,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   int dtype, pt_stream stream);
+/* The same update over positions [lo, hi) of the flat buffers only, walked in GRADIENT order (a Conv1d k=3 weight's gradient is
+ * tap-major: position i then updates the master element at the transposed place of the same output row), so that a contiguous
+ * range of the flat gradient buffer -- what a reduce-scatter hands one rank -- is a self-contained unit of optimizer work
+ * (data-parallel training with a sharded optimizer pass; replaces DDP + a replicated torch.optim.AdamW, train.py:41-47,67-69,
+ * 115-120).  lo % 4 == 0.  publish != 0: the updated values also overwrite g[lo, hi): an all-gather of the gradient buffer then
+ * carries the new parameters to the other ranks, which adopt them with pt_import_params_range. */
+int pt_adamw_step_range(float* p, float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg,
+                        int64_t n_total, int64_t lo, int64_t hi, const float* gnorm_sq, float max_norm, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int64_t step, int publish, int dtype, pt_stream stream);
+/* master[...] = values[lo, hi) (gradient order, as published by pt_adamw_step_range) + shadow refresh; frozen tensors keep theirs. */
+int pt_import_params_range(float* p, const float* values, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
+                           int64_t lo, int64_t hi, int dtype, pt_stream stream);
 /* shadow refresh only (after load_state_dict). */
 int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
                    int dtype, pt_stream stream);

@@ -129,6 +129,9 @@ SIGNATURES = {
     "pt_sumsq": [_vp, _vp, _i64, _vp],
     "pt_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
                       _i32, _vp],
+    "pt_adamw_step_range": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
+                            _i32, _i32, _vp],
+    "pt_import_params_range": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_pack_shadow": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pt_rvq_decode": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "pt_ddpm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],

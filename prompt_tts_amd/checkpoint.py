@@ -17,6 +17,15 @@ import threading
 import torch
 
 
+def _moment_view(flat, info, p):
+    """A parameter's Adam moment in the parameter's own shape.  The flat moments are indexed like the flat GRADIENT buffer: a
+    Conv1d k=3 weight's gradient (and so its moments) is stored tap-major [Cout][3][Cin] (include/prompt_tts_hip.h, pt_param_seg)."""
+    v = flat[info["off"]:info["off"] + info["n"]]
+    if p.dim() == 3 and p.shape[2] == 3:
+        return v.view(p.shape[0], 3, p.shape[1]).permute(0, 2, 1)
+    return v.view(p.shape)
+
+
 def adamw_state_dict(store, lr, hyper):
     """torch.optim.AdamW.state_dict() for the flat store: per-parameter views of the flat Adam moments."""
     state, ids = {}, []
@@ -26,8 +35,7 @@ def adamw_state_dict(store, lr, hyper):
         info = store.info[id(p)]
         if info["frozen"] or store.adam_m is None:
             continue
-        lo, hi = info["off"], info["off"] + info["n"]
-        state[i] = {"step": step.clone(), "exp_avg": store.adam_m[lo:hi].view(p.shape), "exp_avg_sq": store.adam_v[lo:hi].view(p.shape)}
+        state[i] = {"step": step.clone(), "exp_avg": _moment_view(store.adam_m, info, p), "exp_avg_sq": _moment_view(store.adam_v, info, p)}
     group = {"lr": lr, "betas": tuple(hyper["betas"]), "eps": hyper["eps"], "weight_decay": hyper["weight_decay"], "amsgrad": False,
              "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
              "initial_lr": hyper["lr"], "params": ids}
@@ -56,9 +64,8 @@ def load_adamw_state_dict(store, sd):
         info = store.info[id(p)]
         if tuple(st["exp_avg"].shape) != tuple(p.shape):
             raise RuntimeError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {info['name']} {tuple(p.shape)}")
-        lo, hi = info["off"], info["off"] + info["n"]
-        store.adam_m[lo:hi].view(p.shape).copy_(st["exp_avg"].to(dev))
-        store.adam_v[lo:hi].view(p.shape).copy_(st["exp_avg_sq"].to(dev))
+        _moment_view(store.adam_m, info, p).copy_(st["exp_avg"].to(dev))
+        _moment_view(store.adam_v, info, p).copy_(st["exp_avg_sq"].to(dev))
         steps.add(int(float(st["step"])))
     if len(steps) > 1:
         raise RuntimeError(f"per-parameter step counts differ ({sorted(steps)}): not a checkpoint of this training loop")

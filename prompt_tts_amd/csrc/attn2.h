@@ -20,6 +20,26 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
+// Diagnostic build only (make trace; tools/attn_trace.py): thread 0 of one workgroup in the middle of the grid leaves s_memtime
+// stamps per tile phase.  The stamps go to a buffer nothing else reads; no output depends on them.
+#ifndef A2_TRACE
+#define A2_TRACE 0
+#endif
+#if A2_TRACE
+static __device__ unsigned long long a2_trace_buf[512];
+#define A2_STAMP_(k) do { if ((int)blockIdx.x == (int)(gridDim.x / 2) && threadIdx.x == 0 && (k) < 512) a2_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#if A2_TRACE == 2          // stamps of the dK/dV kernel instead of the dQ kernel's
+#define A2_STAMP(k) do { } while (0)
+#define A2_KV_STAMP(k) A2_STAMP_(k)
+#else
+#define A2_STAMP(k) A2_STAMP_(k)
+#define A2_KV_STAMP(k) do { } while (0)
+#endif
+#else
+#define A2_STAMP(k) do { } while (0)
+#define A2_KV_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x16_t mma32(const bf16x8_t a, const bf16x8_t b, const f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -36,28 +56,31 @@ template <int D> struct A2 {
   static constexpr int DT = D / 32;                         // 32-row tiles over the head dim
   static constexpr int TILE = 64 * RB;                      // one 64-row image
   static constexpr int DMA_PER_THREAD = 64 * NCH / 256;     // LDS-DMA instructions per thread per 64-row image (256 threads)
-  // ROW-read image (ds_read_b128 of the 32x32 A operand: 16 lanes of a read group = 16 different rows, one chunk column):
-  // chunk c of row r lives at chunk c ^ f(r), f(r) = (r / RPL) & (NCH - 1) -- the 16 rows of every read group then cover the
-  // 16 chunk slots of a bank line exactly once for D = 32, 64, 128.
-  __device__ static __forceinline__ int rsw(int r) { return (r / RPL) & (NCH - 1); }
-  __device__ static __forceinline__ int roff(int r, int c) { return r * RB + ((c ^ rsw(r)) << 4); }
-  // TRANSPOSED-read image (ds_read_b64_tr_b16: a 32-lane half reads 4 rows x 64 contiguous bytes): the 64-byte block b of row r
-  // lives at block b ^ g(r), g(r) = (r / RPL) & (NB - 1) -- the 4 rows then sit on 4 different quarters of the bank line.
-  __device__ static __forceinline__ int tsw(int r) { return ((r / RPL) & (NB - 1)) << 2; }
-  __device__ static __forceinline__ int toff(int r, int c) { return r * RB + ((c ^ tsw(r)) << 4); }
+  // ONE image serves row reads AND transposed reads (the backward kernels read K, Q and dO both ways): chunk c of row r lives
+  // at chunk c ^ sw(r),  sw(r) = (((r / RPL) & (NB - 1)) << 2) | ((r >> 2) & 3).
+  //   row read (ds_read_b128 of the 32x32 A operand): the 16 lanes of a read group hold 16 different rows at one chunk column;
+  //     with this swizzle they cover the 16 chunk slots of a 256-byte bank line exactly once (D = 32, 64, 128; checked by
+  //     enumeration of the four lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32);
+  //   transposed read (ds_read_b64_tr_b16): a 32-lane half reads 4 consecutive rows x 64 contiguous bytes; the high swizzle
+  //     bits move the 64-byte block of rows r and r + RPL.. to different quarters of the bank line.
+  __device__ static __forceinline__ int sw(int r) { return (((r / RPL) & (NB - 1)) << 2) | ((r >> 2) & 3); }
+  __device__ static __forceinline__ int off(int r, int c) { return r * RB + (((c ^ sw(r)) & (NCH - 1)) << 4); }
 };
 
-// Per-lane LDS offsets of the fragment reads (loop invariant; tiles 16 / 32 rows further add an immediate).
+// Per-lane LDS offsets of the fragment reads (loop invariant; tiles 16 / 32 rows further add an immediate: sw() of a row
+// does not change when a multiple of 16 is added to rows that differ only in such an offset).
 template <int D> struct A2Offsets {
   using C = A2<D>;
-  int rowread[C::KS];     // row-read image: row (lane & 31), chunk 2 ks + h
-  int trread[C::DT];      // transposed-read image: row 4h + q, bytes 64 dt + 32 (G & 1) + 8 p   (lane = 16 G + 4 q + p)
+  int rowread[C::KS];        // row read: row (lane & 31), chunk 2 ks + h
+  int trread[2][C::DT];      // transposed read w: row 8 w + 4 h + q, bytes 64 dt + 32 (G & 1) + 8 p   (lane = 16 G + 4 q + p)
   __device__ __forceinline__ void init(int lane) {
     const int r = lane & 31, h = lane >> 5, G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) rowread[ks] = C::roff(r, 2 * ks + h);
+    for (int ks = 0; ks < C::KS; ++ks) rowread[ks] = C::off(r, 2 * ks + h);
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) trread[dt] = C::toff(4 * h + q, 4 * dt + 2 * (G & 1) + (pp >> 1)) + ((pp & 1) << 3);
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) trread[w][dt] = C::off(8 * w + 4 * h + q, 4 * dt + 2 * (G & 1) + (pp >> 1)) + ((pp & 1) << 3);
   }
 };
 
@@ -67,11 +90,11 @@ template <int D> __device__ __forceinline__ bf16x8_t a2_read_rows(const char* im
 }
 // A operand fragment transposed: lane gets column 32 dt + (lane & 31) of image rows k0 + {4h..4h+3, 8+4h..8+4h+3} (k0 % 16 == 0).
 // EXEC must be all ones.
-template <int D> __device__ __forceinline__ bf16x8_t a2_read_tr(const char* img, int off, int k0) {
+template <int D> __device__ __forceinline__ bf16x8_t a2_read_tr(const char* img, int off_lo, int off_hi, int k0) {
   typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + k0 * A2<D>::RB));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off + (k0 + 8) * A2<D>::RB));
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off_lo + k0 * A2<D>::RB));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off_hi + k0 * A2<D>::RB));
   const s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, r);
 }
@@ -98,29 +121,70 @@ __device__ __forceinline__ float a2_half_sum(float v) {
   return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
 }
 
-typedef __attribute__((address_space(1))) const void a2_gptr;
 typedef __attribute__((address_space(3))) void a2_lptr;
 
+// One LDS-DMA wave-instruction (64 lanes x 16 bytes -> 1 KiB of LDS at `lds`, which must be wave-uniform), as INLINE ASM.
+// Through the builtin, hipcc knows the instruction writes LDS: it then puts an s_waitcnt vmcnt(0) in front of the next ds_read
+// that might alias -- with a dynamically indexed ring that is every read of the tile being multiplied, i.e. the load of tile t + 1
+// was waited for in the middle of tile t and the double buffering hid nothing.  The asm form is invisible to that pass: the
+// kernels wait themselves (a2_dma_wait() in front of the barrier that publishes the tile).  M0 is written inside the statement
+// and not used by anything else in these kernels (no movrel, GWS or DMA builtins).
+__device__ __forceinline__ void a2_dma16(const void* gsrc, char* lds) {
+  const uint32_t a = (uint32_t)(uintptr_t)(a2_lptr*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory");
+}
+__device__ __forceinline__ void a2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The same with the tile's base address in SGPRs and a 32-bit per-lane byte offset (the `saddr` form): the per-lane part is
+// loop invariant, so a tile costs no vector address arithmetic at all.
+__device__ __forceinline__ void a2_dma16s(uint32_t voff, const void* sbase, char* lds) {
+  const uint32_t a = (uint32_t)(uintptr_t)(a2_lptr*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory");
+}
+
 // HBM -> LDS staging of a 64-row image by LDS-DMA.  One wave-instruction fills 1 KiB (lane * 16 bytes from a wave-uniform LDS
-// base); image slot q = tid + 256 i is row q / NCH, physical chunk q % NCH, i.e. LOGICAL chunk (q % NCH) ^ swizzle(row): the
-// swizzle is applied to the per-lane source address.  Rows past `limit` re-read row limit - 1 (finite data; masked by the caller).
-template <int D, bool TR> struct A2Stage {
+// base); image slot q = tid + 256 i is row q / NCH, physical chunk q % NCH, i.e. LOGICAL chunk (q % NCH) ^ sw(row): the
+// swizzle is applied to the per-lane source address.  Rows past the tensor's end re-read its last row (finite data; masked by
+// the caller): only the last, ragged tile takes that path.
+// NT = threads of the workgroup (256 or 512): the image's 64 NCH chunks are dealt out over NT threads; when the image has fewer
+// chunks than threads (D = 32 with 512 threads) only the first waves issue (wave-uniform predicate).
+template <int D, int NT = 256> struct A2Stage {
   using C = A2<D>;
-  int row[C::DMA_PER_THREAD], col[C::DMA_PER_THREAD];       // image row, element column of this thread's chunks
-  __device__ __forceinline__ void init(int tid) {
+  static constexpr int SLOTS = 64 * C::NCH;
+  static constexpr int PER = (SLOTS + NT - 1) / NT;
+  uint32_t voff[PER];      // byte offset of this thread's chunks from the tile's first row
+  int64_t ld;
+  __device__ __forceinline__ void init(int tid, int64_t ld_) {
+    ld = ld_;
 #pragma unroll
-    for (int i = 0; i < C::DMA_PER_THREAD; ++i) {
-      const int q = tid + 256 * i, r = q / C::NCH, cp = q % C::NCH;
-      row[i] = r;
-      col[i] = (cp ^ (TR ? C::tsw(r) : C::rsw(r))) * 8;
+    for (int i = 0; i < PER; ++i) {
+      const int q = (tid + NT * i) % SLOTS, r = q / C::NCH, cp = q % C::NCH;
+      voff[i] = (uint32_t)(r * ld * 2 + ((cp ^ C::sw(r)) & (C::NCH - 1)) * 16);
     }
   }
-  __device__ __forceinline__ void issue(const bf16_t* base, int64_t ld, int row0, int limit, char* img, int wave) const {
+  // base: the tensor's (batch, head) slice; row0 (wave-uniform): first row of the tile; limit: rows of the tensor
+  __device__ __forceinline__ void issue(const bf16_t* base, int row0, int limit, char* img, int wave, int tid) const {
+    // the tile's base address is wave-uniform; say so (an "s" operand the compiler believes divergent is handed over in VGPRs)
+    const uint64_t ta = (uint64_t)(base + (int64_t)row0 * ld);
+    // (readfirstlane returns a SIGNED int: both halves go through uint32_t, or a low half with bit 31 set sign-extends into
+    // the high half -- an address fault that depends on where the allocator put the tensor)
+    const uint32_t ta_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta >> 32));
+    const uint32_t ta_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta);
+    const bf16_t* tile = reinterpret_cast<const bf16_t*>(((uint64_t)ta_hi << 32) | (uint64_t)ta_lo);
+    if (row0 + 64 <= limit) {
 #pragma unroll
-    for (int i = 0; i < C::DMA_PER_THREAD; ++i) {
-      int r = row0 + row[i]; r = r < limit ? r : limit - 1;
-      const bf16_t* src = base + (int64_t)r * ld + col[i];
-      __builtin_amdgcn_global_load_lds((a2_gptr*)src, (a2_lptr*)(img + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      for (int i = 0; i < PER; ++i)
+        if (wave * 64 + NT * i < SLOTS) a2_dma16s(voff[i], tile, img + (wave * 64 + NT * i) * 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (wave * 64 + NT * i < SLOTS) {
+          const int q = tid + NT * i, cp = q % C::NCH;
+          int r = q / C::NCH;
+          const int sw = C::sw(r);
+          r = row0 + r < limit ? r : limit - 1 - row0;
+          a2_dma16s((uint32_t)(r * ld * 2 + ((cp ^ sw) & (C::NCH - 1)) * 16), tile, img + (wave * 64 + NT * i) * 16);
+        }
     }
   }
 };

@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(cons
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Nk * p.ldk + hd * D;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Nk * p.ldv + hd * D;
 
-  A2Stage<D, false> stK; A2Stage<D, true> stV;
-  stK.init(tid); stV.init(tid);
-  stK.issue(K, p.ldk, 0, p.Nk, smem, wave);
-  stV.issue(V, p.ldv, 0, p.Nk, smem + TILE, wave);
+  A2Stage<D> stK, stV;
+  stK.init(tid, p.ldk); stV.init(tid, p.ldv);
+  stK.issue(K, 0, p.Nk, smem, wave, tid);
+  stV.issue(V, 0, p.Nk, smem + TILE, wave, tid);
 
   // Q' fragments: B operand, column = query q0 + r, k = 16 ks + 8 h + j; pre-multiplied by scale * log2(e)
   const float sl2 = p.scale * PT_LOG2E;
@@ -56,24 +56,40 @@ __global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(cons
   for (int dt = 0; dt < DT; ++dt) o[dt] = splat16(0.f);
   float m = 0.f, l = 0.f;                 // m: reference maximum of this lane's query (log2 units); l: this lane half's partial row sum
   const int qrow = q0 + r;
+  a2_dma_wait();
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) {
-      stK.issue(K, p.ldk, (t + 1) * 64, p.Nk, smem + (cur ^ 1) * 2 * TILE, wave);
-      stV.issue(V, p.ldv, (t + 1) * 64, p.Nk, smem + (cur ^ 1) * 2 * TILE + TILE, wave);
-    }
     const char* kimg = smem + cur * 2 * TILE;
     const char* vimg = kimg + TILE;
 
     // S'^T = K Q'^T - m  (the first tile starts from 0: its maximum becomes the reference)
+    // (all fragment reads of the phase are issued before its first MFMA: the waits in front of the MFMAs are then COUNTED,
+    // lgkmcnt(7), (6), ... -- left alone, hipcc reads two fragments, waits for both, multiplies, and exposes the LDS latency
+    // once per MFMA)
     f32x16_t s[2];
+    {
+      bf16x8_t ka[2][KS];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      s[kt] = splat16(-m);
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kt] = mma32(a2_read_rows<D>(kimg, fo.rowread[ks], 32 * kt), qf[ks], s[kt]);
+        for (int ks = 0; ks < KS; ++ks) ka[kt][ks] = a2_read_rows<D>(kimg, fo.rowread[ks], 32 * kt);
+      __builtin_amdgcn_sched_barrier(0);
+      s[0] = splat16(-m);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[0] = mma32(ka[0][ks], qf[ks], s[0]);
+      // the next tile's LDS-DMA is issued HERE, in the shadow of the MFMAs just issued (a DMA piece costs the wave 60 - 180
+      // cycles of issue: at the top of the loop nothing overlapped them)
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ntiles) {
+        stK.issue(K, (t + 1) * 64, p.Nk, smem + (cur ^ 1) * 2 * TILE, wave, tid);
+        stV.issue(V, (t + 1) * 64, p.Nk, smem + (cur ^ 1) * 2 * TILE + TILE, wave, tid);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      s[1] = splat16(-m);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[1] = mma32(ka[1][ks], qf[ks], s[1]);
     }
     const int key0 = t * 64;
     if (key0 + 64 > nk || p.causal) {
@@ -108,15 +124,21 @@ __global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(cons
       for (int e = 0; e < 16; ++e) { const float pv = __builtin_amdgcn_exp2f(s[kt][e]); s[kt][e] = pv; rs += pv; }
     l += rs;
     // O^T += V^T P^T
+    {
+      bf16x8_t va[4][DT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int sk = 0; sk < 2; ++sk) {
-        const bf16x8_t pf = a2_pack(s[kt], sk);
+        for (int dt = 0; dt < DT; ++dt) va[kk][dt] = a2_read_tr<D>(vimg, fo.trread[0][dt], fo.trread[1][dt], 16 * kk);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = mma32(a2_read_tr<D>(vimg, fo.trread[dt], 32 * kt + 16 * sk), pf, o[dt]);
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8_t pf = a2_pack(s[kk >> 1], kk & 1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mma32(va[kk][dt], pf, o[dt]);
       }
-    __syncthreads();          // next tile has landed (vmcnt(0) in front of the barrier) and this one is free to be overwritten
+    }
+    a2_dma_wait();            // this wave's pieces of the next tile have landed ...
+    __syncthreads();          // ... and so have everyone's; the tile just multiplied is free to be overwritten
   }
 
   // epilogue: lane holds O^T[d = 32 dt + (e & 3) + 8 (e >> 2) + 4 h][q = q0 + r]

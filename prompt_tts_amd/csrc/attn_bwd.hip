@@ -343,11 +343,17 @@ int pt_attn_fill_params(const pt_attn_desc* d, int dtype, bool bwd, AttnParams& 
   return PT_OK;
 }
 
+int pt_attn2_bwd(const AttnParams& p, int D, hipStream_t s);        // attn2_bwd.hip
+
 extern "C" int pt_attn_bwd(const pt_attn_desc* d, int dtype, pt_stream stream) {
   AttnParams p;
   int st = pt_attn_fill_params(d, dtype, true, p);
   if (st) return st;
   hipStream_t s = (hipStream_t)stream;
+  // bf16: the second-generation kernels (attn2_bwd.hip) are selected by PT_ATTN_BWD_V2 (default set from measurements:
+  // tools/attn_probe.py, profiles/r03_attn_*)
+  static const int v2 = pt_env_int("PT_ATTN_V2", 1) && pt_env_int("PT_ATTN_BWD_V2", 0);
+  if (dtype == PT_BF16 && v2) return pt_attn2_bwd(p, (int)d->D, s);
 #define BWD(TT) \
   switch (d->D) { case 32: return launch_bwd<TT, 32>(p, s); case 64: return launch_bwd<TT, 64>(p, s); \
                   case 128: return launch_bwd<TT, 128>(p, s); default: return PT_ERR_SHAPE; }

@@ -39,12 +39,21 @@ __device__ __forceinline__ void shadow_store(T* shadow, const pt_param_seg& sg, 
   }
 }
 
-template <typename T, bool UPDATE>
-__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// MODE 0: pack the shadow from the master (no update).  MODE 1: clip + AdamW + shadow refresh.  MODE 2: IMPORT -- the new
+// parameter values are read from `g` (a peer rank computed them: sharded optimizer, prompt_tts_amd/parallel.py) and written to
+// the master and the shadow.  The kernel walks flat positions [lo, hi) in GRADIENT order: for every tensor but a Conv1d k = 3
+// weight that is the master order; a conv weight's gradient (and shadow) is tap-major [Cout][3][Cin] while its master is
+// [Cout][Cin][3], so position i of the walk addresses g[i] and the master element at the transposed place of the same output
+// row.  Walking in gradient order makes a contiguous range of the flat GRADIENT buffer (what a reduce-scatter hands a rank) a
+// self-contained unit of work.  MODE 1 with `publish`: the new value also overwrites g[i] (the gradient is dead then), so an
+// all-gather of the gradient buffer distributes the updated parameters.
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, T* __restrict__ shadow,
-                                                   const pt_param_seg* __restrict__ seg, int n_seg, int64_t n_total,
+                                                   const pt_param_seg* __restrict__ seg, int n_seg, int64_t lo, int64_t hi,
                                                    const float* __restrict__ gnorm_sq, float max_norm, float lr, float b1,
-                                                   float b2, float eps, float wd, float bc1, float bc2) {
+                                                   float b2, float eps, float wd, float bc1, float bc2, int publish) {
+  constexpr bool UPDATE = MODE == 1, IMPORT = MODE == 2;
   float clip = 1.f;
   if (UPDATE && gnorm_sq) {
     const float nrm = sqrtf(*gnorm_sq);
@@ -52,23 +61,29 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
   }
   __shared__ int s_first;
   const float decay = 1.f - lr * wd, rbc2 = 1.f / sqrtf(bc2), step = lr / bc1;
-  for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < n_total; base += (int64_t)gridDim.x * CHUNK) {
+  for (int64_t base = lo + (int64_t)blockIdx.x * CHUNK; base < hi; base += (int64_t)gridDim.x * CHUNK) {
     __syncthreads();
     if (threadIdx.x == 0) s_first = find_seg(seg, n_seg, base);     // one binary search per 4096-element chunk
     __syncthreads();
-    // Quads: every tensor starts on a multiple of 4 elements, so 4 consecutive elements never straddle two tensors.  Plain
-    // (layout 0) quads that lie wholly inside their tensor move as 16-byte loads / stores of p, g, m, v (and an 8-byte shadow
-    // store); conv k=3 tensors (their gradient and shadow are tap-major), tails and padding take the element path.
+    // Quads: every tensor starts on a multiple of 4 elements (and lo is one), so 4 consecutive elements never straddle two
+    // tensors.  Plain (layout 0) quads that lie wholly inside their tensor move as 16-byte loads / stores of p, g, m, v (and an
+    // 8-byte shadow store); conv k=3 tensors, tails and padding take the element path.
     for (int k = threadIdx.x * 4; k < CHUNK; k += NT * 4) {
       const int64_t i = base + k;
-      if (i >= n_total) break;
+      if (i >= hi) break;
       int si = s_first;
       while (si + 1 < n_seg && seg[si + 1].offset <= i) ++si;       // tensors are mostly larger than a chunk: 0-1 steps
       const pt_param_seg sg = seg[si];
       const int64_t local = i - sg.offset;
       if (local >= sg.numel) continue;                 // alignment padding between tensors
-      if (sg.layout != 1 && local + 3 < sg.numel && i + 3 < n_total && (sg.layout == 0 || (sg.cin & 3) == 0)) {
-        f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + i);
+      if (sg.layout != 1 && local + 3 < sg.numel && i + 3 < hi && (sg.layout == 0 || (sg.cin & 3) == 0)) {
+        f32x4_t pv;
+        if (IMPORT) {
+          pv = *reinterpret_cast<const f32x4_t*>(g + i);
+          if (!sg.frozen) *reinterpret_cast<f32x4_t*>(p + i) = pv; else pv = *reinterpret_cast<const f32x4_t*>(p + i);
+        } else {
+          pv = *reinterpret_cast<const f32x4_t*>(p + i);
+        }
         if (UPDATE && !sg.frozen) {
           const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i);
           f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + i), vv = *reinterpret_cast<const f32x4_t*>(v + i);
@@ -82,27 +97,33 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
           *reinterpret_cast<f32x4_t*>(m + i) = mv; *reinterpret_cast<f32x4_t*>(v + i) = vv;
           *reinterpret_cast<f32x4_t*>(p + i) = pv;
         }
+        if (UPDATE && publish) *reinterpret_cast<f32x4_t*>(g + i) = pv;
         store4<T>(shadow + sg.shadow_offset + (sg.layout == 2 ? geglu_shadow_index(sg, local) : local), pv[0], pv[1], pv[2], pv[3]);
         continue;
       }
-      for (int e = 0; e < 4 && local + e < sg.numel && i + e < n_total; ++e) {
-        const int64_t ie = i + e, le = local + e;
+      for (int e = 0; e < 4 && local + e < sg.numel && i + e < hi; ++e) {
+        const int64_t ge_i = i + e;                  // position in the gradient buffer
+        int64_t le = local + e;                      // element of the tensor in MASTER order
+        if (sg.layout == 1) {                        // conv k=3: gradient position (co, tap, ci) <-> master element (co, ci, tap)
+          const int64_t per_co = (int64_t)sg.cin * 3;
+          const int64_t co = le / per_co; const int rem = (int)(le - co * per_co);
+          const int tap = rem / sg.cin, ci = rem - tap * sg.cin;
+          le = co * per_co + (int64_t)ci * 3 + tap;
+        }
+        const int64_t ie = sg.offset + le;
         float pv = p[ie];
+        if (IMPORT && !sg.frozen) { pv = g[ge_i]; p[ie] = pv; }
         if (UPDATE && !sg.frozen) {
-          int64_t gi = ie;
-          if (sg.layout == 1) {                        // conv k=3 gradients live as [Cout][3][Cin]
-            const int64_t per_co = (int64_t)sg.cin * 3;
-            const int64_t co = le / per_co; const int rem = (int)(le - co * per_co);
-            const int ci = rem / 3, tap = rem - ci * 3;
-            gi = sg.offset + (co * 3 + tap) * sg.cin + ci;
-          }
-          const float gv = g[gi] * clip;
-          const float mv = b1 * m[ie] + (1.f - b1) * gv;
-          const float vv = b2 * v[ie] + (1.f - b2) * gv * gv;
-          m[ie] = mv; v[ie] = vv;
+          // the Adam moments live at the GRADIENT position (for a conv weight: tap-major, like g): whoever owns a range of
+          // the gradient buffer owns exactly the moments at the same positions
+          const float gv = g[ge_i] * clip;
+          const float mv = b1 * m[ge_i] + (1.f - b1) * gv;
+          const float vv = b2 * v[ge_i] + (1.f - b2) * gv * gv;
+          m[ge_i] = mv; v[ge_i] = vv;
           pv = pv * decay - step * (mv / (sqrtf(vv) * rbc2 + eps));
           p[ie] = pv;
         }
+        if (UPDATE && publish) g[ge_i] = pv;
         shadow_store<T>(shadow, sg, le, pv);
       }
     }
@@ -149,36 +170,53 @@ extern "C" int pt_transpose_batch(const pt_transpose_seg* segs_dev, int64_t n_se
   return PT_OK;
 }
 
+static int adamw_launch(int mode, float* p, float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg,
+                        int64_t lo, int64_t hi, const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, int publish, int dtype, hipStream_t s) {
+  const float bc1 = mode == 1 ? 1.f - powf(beta1, (float)step) : 1.f, bc2 = mode == 1 ? 1.f - powf(beta2, (float)step) : 1.f;
+  int64_t blocks = (hi - lo + CHUNK - 1) / CHUNK;
+  if (blocks > 4096) blocks = 4096;
+#define ADAMW_GO(TT, MODE) hipLaunchKernelGGL((adamw_kernel<TT, MODE>), dim3((unsigned)blocks), dim3(NT), 0, s, p, g, m, v, (TT*)shadow, \
+                                              seg_dev, (int)n_seg, lo, hi, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, publish)
+  if (dtype == PT_F32) { if (mode == 0) ADAMW_GO(float, 0); else if (mode == 1) ADAMW_GO(float, 1); else ADAMW_GO(float, 2); }
+  else if (dtype == PT_BF16) { if (mode == 0) ADAMW_GO(bf16_t, 0); else if (mode == 1) ADAMW_GO(bf16_t, 1); else ADAMW_GO(bf16_t, 2); }
+  else return PT_ERR_DTYPE;
+#undef ADAMW_GO
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
 extern "C" int pt_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev,
                              int64_t n_seg, int64_t n_total, const float* gnorm_sq, float max_norm, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int64_t step, int dtype, pt_stream stream) {
   if (n_seg <= 0 || n_total <= 0 || step <= 0) return PT_ERR_SHAPE;
   if (!p || !g || !m || !v || !shadow || !seg_dev) return PT_ERR_ARG;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  int64_t blocks = (n_total + CHUNK - 1) / CHUNK;
-  if (blocks > 4096) blocks = 4096;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32)
-    hipLaunchKernelGGL((adamw_kernel<float, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p, g, m, v, (float*)shadow, seg_dev, (int)n_seg, n_total, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
-  else if (dtype == PT_BF16)
-    hipLaunchKernelGGL((adamw_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p, g, m, v, (bf16_t*)shadow, seg_dev, (int)n_seg, n_total, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
-  else return PT_ERR_DTYPE;
-  PT_LAUNCH_CHECK();
-  return PT_OK;
+  return adamw_launch(1, p, const_cast<float*>(g), m, v, shadow, seg_dev, n_seg, 0, n_total, gnorm_sq, max_norm, lr, beta1, beta2, eps,
+                      weight_decay, step, 0, dtype, (hipStream_t)stream);
+}
+
+extern "C" int pt_adamw_step_range(float* p, float* g, float* m, float* v, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg,
+                                   int64_t n_total, int64_t lo, int64_t hi, const float* gnorm_sq, float max_norm, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int64_t step, int publish, int dtype,
+                                   pt_stream stream) {
+  if (n_seg <= 0 || n_total <= 0 || step <= 0 || lo < 0 || hi > n_total || lo >= hi || (lo & 3)) return PT_ERR_SHAPE;
+  if (!p || !g || !m || !v || !shadow || !seg_dev) return PT_ERR_ARG;
+  return adamw_launch(1, p, g, m, v, shadow, seg_dev, n_seg, lo, hi, gnorm_sq, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                      publish ? 1 : 0, dtype, (hipStream_t)stream);
+}
+
+extern "C" int pt_import_params_range(float* p, const float* values, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg,
+                                      int64_t n_total, int64_t lo, int64_t hi, int dtype, pt_stream stream) {
+  if (n_seg <= 0 || n_total <= 0 || lo < 0 || hi > n_total || lo >= hi || (lo & 3)) return PT_ERR_SHAPE;
+  if (!p || !values || !shadow || !seg_dev) return PT_ERR_ARG;
+  return adamw_launch(2, p, const_cast<float*>(values), nullptr, nullptr, shadow, seg_dev, n_seg, lo, hi, nullptr, 0.f, 0.f, 0.f, 0.f,
+                      0.f, 0.f, 1, 0, dtype, (hipStream_t)stream);
 }
 
 extern "C" int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, int64_t n_seg, int64_t n_total,
                               int dtype, pt_stream stream) {
   if (n_seg <= 0 || n_total <= 0) return PT_ERR_SHAPE;
   if (!p || !shadow || !seg_dev) return PT_ERR_ARG;
-  int64_t blocks = (n_total + CHUNK - 1) / CHUNK;
-  if (blocks > 4096) blocks = 4096;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == PT_F32)
-    hipLaunchKernelGGL((adamw_kernel<float, false>), dim3((unsigned)blocks), dim3(NT), 0, s, const_cast<float*>(p), nullptr, nullptr, nullptr, (float*)shadow, seg_dev, (int)n_seg, n_total, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
-  else if (dtype == PT_BF16)
-    hipLaunchKernelGGL((adamw_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(NT), 0, s, const_cast<float*>(p), nullptr, nullptr, nullptr, (bf16_t*)shadow, seg_dev, (int)n_seg, n_total, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
-  else return PT_ERR_DTYPE;
-  PT_LAUNCH_CHECK();
-  return PT_OK;
+  return adamw_launch(0, const_cast<float*>(p), nullptr, nullptr, nullptr, shadow, seg_dev, n_seg, 0, n_total, nullptr, 0.f, 0.f, 0.f,
+                      0.f, 0.f, 0.f, 1, 0, dtype, (hipStream_t)stream);
 }

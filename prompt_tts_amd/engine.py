@@ -354,6 +354,38 @@ class ParamStore:
         return gnorm_sq
 
 
+def adamw_step_sharded(st, reducer, lr, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6, max_norm=1.0):
+    """The optimizer step of a data-parallel rank under parallel.ShardedGradReducer (after reducer.finish()): global gradient
+    norm from the slice norms, clip + AdamW on the slices this rank owns (+ the redundantly updated bucket tails), the new values
+    published through the gradient buffer, all-gathered, and adopted into master + shadow.  Returns the squared global norm."""
+    if st.adam_m is None:
+        st.adam_m = torch.zeros_like(st.flat_p); st.adam_v = torch.zeros_like(st.flat_p)
+    own, tails, foreign = reducer.owned_ranges(), reducer.tail_ranges(), reducer.foreign_ranges()
+    gnorm_sq = torch.zeros(1, dtype=torch.float32, device=st.device)
+    for lo, hi in own:
+        ops.sumsq(st.flat_g[lo:hi], gnorm_sq)
+    if reducer.rank == 0:                        # the tails are identical everywhere: counted once
+        for lo, hi in tails:
+            ops.sumsq(st.flat_g[lo:hi], gnorm_sq)
+    reducer.global_sum(gnorm_sq)
+    st.step_count += 1
+    st.ensure_shadow_fresh()
+    for lo, hi in own:
+        ops.adamw_step_range(st.flat_p, st.flat_g, st.adam_m, st.adam_v, st.shadow, st.seg_dev, st.n_seg, lo, hi, gnorm_sq, max_norm,
+                             lr, betas[0], betas[1], eps, weight_decay, st.step_count, publish=True)
+    for lo, hi in tails:
+        if lo % 4:
+            raise RuntimeError("sharded optimizer: bucket tails must start on a quad (ParamStore spans are 64-element aligned)")
+        ops.adamw_step_range(st.flat_p, st.flat_g, st.adam_m, st.adam_v, st.shadow, st.seg_dev, st.n_seg, lo, hi, gnorm_sq, max_norm,
+                             lr, betas[0], betas[1], eps, weight_decay, st.step_count, publish=False)
+    reducer.allgather_published()
+    for lo, hi in foreign:
+        ops.import_params_range(st.flat_p, st.flat_g, st.shadow, st.seg_dev, st.n_seg, lo, hi)
+    st.shadow_dirty = False
+    st.shadow_version += 1
+    return gnorm_sq
+
+
 # ---------------------------------------------------------------------------------------------------------
 # layer executors (x, dy are token-major 2-D tensors)
 # ---------------------------------------------------------------------------------------------------------

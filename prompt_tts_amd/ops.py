@@ -301,6 +301,19 @@ def adamw_step(p, g, m, v, shadow, seg_dev, n_seg, gnorm_sq, max_norm, lr, beta1
                             max_norm, lr, beta1, beta2, eps, wd, step, pt_dtype(shadow), _stream()), "pt_adamw_step")
 
 
+def adamw_step_range(p, g, m, v, shadow, seg_dev, n_seg, lo, hi, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, step, publish):
+    """The fused AdamW over flat positions [lo, hi) in gradient order; publish: the new values overwrite g[lo:hi]."""
+    check(lib.pt_adamw_step_range(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(seg_dev), n_seg, p.numel(), lo, hi, _p(gnorm_sq),
+                                  max_norm, lr, beta1, beta2, eps, wd, step, int(publish), pt_dtype(shadow), _stream()),
+          "pt_adamw_step_range")
+
+
+def import_params_range(p, values, shadow, seg_dev, n_seg, lo, hi):
+    """master / shadow <- values[lo:hi] (gradient order; what a peer rank published with adamw_step_range)."""
+    check(lib.pt_import_params_range(_p(p), _p(values), _p(shadow), _p(seg_dev), n_seg, p.numel(), lo, hi, pt_dtype(shadow),
+                                     _stream()), "pt_import_params_range")
+
+
 def pack_shadow(p, shadow, seg_dev, n_seg):
     check(lib.pt_pack_shadow(_p(p), _p(shadow), _p(seg_dev), n_seg, p.numel(), pt_dtype(shadow), _stream()),
           "pt_pack_shadow")

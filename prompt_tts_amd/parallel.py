@@ -121,11 +121,135 @@ class GradReducer:
                 w.wait()
 
 
-def attach(model, process_group=None, bucket_bytes=64 << 20):
-    """Create a reducer over model.store.flat_g and hook it into the model's backward."""
+class ShardedGradReducer(GradReducer):
+    """Reduce-scatter -> sharded clip + AdamW -> all-gather (MI355X-first form of the DDP + replicated-AdamW pair of
+    train.py:41-47,67-69,115-120).
+
+    xGMI is point-to-point, so an all-reduce IS a reduce-scatter followed by an all-gather; issuing the two halves ourselves
+    puts the optimizer between them: every bucket (a contiguous range of the flat gradient buffer, announced by the backward
+    like GradReducer's) is reduce-scattered in place on the communication stream while backward continues, so rank r ends up
+    with the summed gradient of slice r of every bucket and updates ONLY those parameters (1/W of the 28-byte-per-parameter
+    optimizer pass; Adam moments are only ever touched on their owner).  The updated values overwrite the gradient slice
+    (pt_adamw_step_range, publish) and ONE in-place all-gather per bucket carries them to the other ranks, which adopt them into
+    master + shadow (pt_import_params_range).  The global gradient norm is the sum of the ranks' slice norms (a 4-byte
+    all-reduce).  Same bytes on the links as the all-reduce, one collective per bucket and direction.
+    A bucket whose body is not a multiple of 4 W elements keeps a tail (< 4 W elements; and a head of < 4 if it does not
+    start on a quad) that is all-reduced and updated redundantly on every rank.  The bucket geometry must be the same every step (the moments live on the owner): it is
+    recorded on the first step and checked afterwards."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+        self.buckets = []           # this step's (head_lo, lo, shard, tail_lo, hi), see _split
+        self._geometry = None
+
+    def begin(self):
+        super().begin()
+        self.buckets = []
+
+    def _split(self, lo, hi):
+        """(head_lo, lo, shard, tail_lo, hi): body [lo, lo + W shard) with lo % 4 == 0 (the optimizer moves 16-byte quads), the
+        head [head_lo, lo) and the tail [tail_lo, hi) are all-reduced.  ParamStore spans are 64-element aligned: no head there."""
+        body_lo = min((lo + 3) // 4 * 4, hi)
+        shard = (hi - body_lo) // (4 * self.world) * 4
+        return lo, body_lo, shard, body_lo + self.world * shard, hi
+
+    def _collect(self, ranges):
+        for lo, hi in ranges:
+            head_lo, lo, shard, tail_lo, hi = b = self._split(lo, hi)
+            self.buckets.append(b)
+            if shard:
+                body = self.flat[lo:tail_lo]
+                mine = body[self.rank * shard:(self.rank + 1) * shard]
+                w = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.pg, async_op=not self.cuda)
+                if not self.cuda:
+                    self._work.append(w)
+            for a, e in ((head_lo, lo), (tail_lo, hi)):
+                if e > a:
+                    w = dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=not self.cuda)
+                    if not self.cuda:
+                        self._work.append(w)
+
+    def _flush(self):
+        if not self._pending:
+            return
+        ranges = self._merge(self._pending)
+        self._pending, self._pending_bytes = [], 0
+        if self.cuda:
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                if self.pre_flush is not None:
+                    self.pre_flush()
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self.stream)
+                self._collect(ranges)
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self.stream)
+                    self._ev.append((e0, e1, sum(4 * (hi - lo) for lo, hi in ranges)))
+        else:
+            self._collect(ranges)
+        self._done += ranges; self.launched += ranges
+
+    def finish(self):
+        super().finish()
+        geo = tuple(self.buckets)
+        if self._geometry is None:
+            self._geometry = geo
+        elif geo != self._geometry:
+            raise RuntimeError("sharded optimizer: the gradient buckets changed between steps (the Adam moments live on "
+                               "the rank that owned them before)")
+
+    # -- what the optimizer needs -------------------------------------------------------------------------------------
+    def owned_ranges(self):
+        """[(lo, hi)] this rank updates and publishes, merged."""
+        return self._merge([(lo + self.rank * sh, lo + (self.rank + 1) * sh) for _, lo, sh, _, _ in self.buckets if sh])
+
+    def tail_ranges(self):
+        """Heads and tails: all-reduced, updated redundantly by every rank (a few elements per bucket)."""
+        return [(a, e) for h, lo, _, t, hi in self.buckets for a, e in ((h, lo), (t, hi)) if e > a]
+
+    def foreign_ranges(self):
+        out = []
+        for _, lo, sh, tail_lo, _ in self.buckets:
+            if sh and self.rank > 0:
+                out.append((lo, lo + self.rank * sh))
+            if sh and self.rank + 1 < self.world:
+                out.append((lo + (self.rank + 1) * sh, tail_lo))
+        return self._merge(out)
+
+    def allgather_published(self, buf=None):
+        """In-place all-gather of every bucket body of `buf` (default: the gradient buffer, which holds the published
+        parameters after the sharded update; also used for the Adam moments when a checkpoint needs them whole)."""
+        buf = self.flat if buf is None else buf
+        work = []
+        for _, lo, sh, tail_lo, _ in self.buckets:
+            if not sh:
+                continue
+            body = buf[lo:tail_lo]
+            mine = body[self.rank * sh:(self.rank + 1) * sh]
+            src = mine if self.cuda else mine.clone()            # the CPU backends do not take an aliased input
+            w = dist.all_gather_into_tensor(body, src, group=self.pg, async_op=not self.cuda)
+            if not self.cuda:
+                work.append(w)
+        for w in work:
+            w.wait()
+
+    def global_sum(self, t):
+        """Sum of a (1,) tensor over the ranks (the squared gradient norm of the slices)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t
+
+
+def attach(model, process_group=None, bucket_bytes=64 << 20, sharded=None):
+    """Create a reducer over model.store.flat_g and hook it into the model's backward.  sharded (default: PT_DP_SHARDED=1):
+    reduce-scatter + sharded optimizer + all-gather (ShardedGradReducer) instead of the all-reduce + replicated optimizer."""
     st = model.store
-    r = GradReducer(st.flat_g, lambda m: st.span(list(m.parameters())) if any(True for _ in m.parameters()) else (0, 0),
-                    process_group, bucket_bytes)
+    if sharded is None:
+        sharded = __import__("os").environ.get("PT_DP_SHARDED", "0") == "1"
+    cls = ShardedGradReducer if sharded else GradReducer
+    r = cls(st.flat_g, lambda m: st.span(list(m.parameters())) if any(True for _ in m.parameters()) else (0, 0),
+            process_group, bucket_bytes)
     if r.cuda and __import__("os").environ.get("PT_DP_HOOK_JOIN", "0") != "1":
         from . import engine as E
 

@@ -301,5 +301,8 @@ class TTSSingleSpeaker(nn.Module):
                                       grad_scale=reducer.grad_scale if reducer is not None else 1.0)
         if reducer is not None:
             reducer.finish()
-        gn = st.adamw_step(lr, betas, eps, weight_decay, max_grad_norm)
+        if reducer is not None and hasattr(reducer, "owned_ranges") and reducer.world > 1:
+            gn = E.adamw_step_sharded(st, reducer, lr, betas, eps, weight_decay, max_grad_norm)
+        else:
+            gn = st.adamw_step(lr, betas, eps, weight_decay, max_grad_norm)
         return loss, gn

@@ -51,12 +51,23 @@ def _worker(rank, world, port, q, mode):
         red.finish()
         torch.cuda.synchronize()
         q.put((rank, float(loss), _named_grads(m), list(red.launched)))
-    else:
+    elif mode == "step":
         red = parallel.attach(m, bucket_bytes=1 << 20)
         loss, gn = m.train_step(*shard, reducer=red)
         torch.cuda.synchronize()
         sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}      # plain arrays: no shared-fd tensors
         q.put((rank, float(loss), float(gn.sqrt()), sd if rank == 0 else None, len(red.launched)))
+    else:                                   # "sharded": reduce-scatter + sharded AdamW + all-gather, two steps
+        red = parallel.attach(m, bucket_bytes=1 << 20, sharded=True)
+        for _ in range(2):
+            loss, gn = m.train_step(*shard, reducer=red)
+        st = m.store
+        red.allgather_published(st.adam_m); red.allgather_published(st.adam_v)       # what a checkpoint does
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        own = sum(hi - lo for lo, hi in red.owned_ranges())
+        q.put((rank, float(loss), float(gn.sqrt()), sd, len(red.launched), own, st.n_total,
+               st.adam_m.cpu().numpy(), st.adam_v.cpu().numpy(), st.shadow.float().cpu().numpy()))
     dist.destroy_process_group()
 
 
@@ -121,3 +132,43 @@ def test_two_rank_step_matches_full_batch(dev):
             continue
         num += float(((got[k] - want[k]).double() ** 2).sum()); den += float(((want[k] - p0[k]).double() ** 2).sum())
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5     # the parameter UPDATE agrees (AdamW amplifies tiny grad noise)
+
+
+def test_two_rank_sharded_optimizer_equals_the_replicated_one(dev):
+    """parallel.ShardedGradReducer (reduce-scatter, AdamW on the owned slices only, all-gather of the published values) against
+    the single-process optimizer on the full batch, two steps: both ranks end with the SAME master weights, shadows and (after
+    the checkpoint's all-gather) Adam moments, and they equal the unsharded result within the gradient-noise bound of
+    test_two_rank_step_matches_full_batch."""
+    import numpy as np
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    torch.manual_seed(0)
+    ref = TTSSingleSpeaker(_cfg(), dtype=torch.float32).to(dev)
+    p0 = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+    for _ in range(2):
+        loss_ref, gn_ref = ref.train_step(*[x.to(dev) for x in _batch(4)])
+    want = {k: v.detach().cpu() for k, v in ref.state_dict().items()}
+    m_ref, v_ref = ref.store.adam_m.cpu().numpy(), ref.store.adam_v.cpu().numpy()
+    r0, r1 = _run("sharded")
+    assert abs(r0[2] - float(gn_ref.sqrt())) < 2e-3 * float(gn_ref.sqrt()) and r0[2] == r1[2]     # one global norm, identical on both
+    assert r0[4] >= 2 and r0[5] + r1[5] > 0.99 * r0[6] and abs(r0[5] - r1[5]) <= 8 * r0[4]        # each rank owns half of the buffer
+    for k in r0[3]:
+        assert np.array_equal(r0[3][k], r1[3][k]), k                                               # replicas stay bit-identical
+    assert np.array_equal(r0[7], r1[7]) and np.array_equal(r0[8], r1[8]) and np.array_equal(r0[9], r1[9])
+    num = den = 0.0
+    for k in want:
+        if "inv_freq" in k:
+            continue
+        got = torch.from_numpy(r0[3][k])
+        num += float(((got - want[k]).double() ** 2).sum()); den += float(((want[k] - p0[k]).double() ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    st = ref.store                                                                                  # moments: same trajectory
+    worst = []
+    for name, p in zip(st.names, st.params):
+        i = st.info[id(p)]
+        a, b = r0[7][i["off"]:i["off"] + i["n"]], m_ref[i["off"]:i["off"] + i["n"]]
+        if np.linalg.norm(b) > 0:
+            worst.append((float(np.linalg.norm(a - b) / np.linalg.norm(b)), name, i["off"], i["n"]))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-2, worst[:8]
+    assert float(np.linalg.norm(r0[7] - m_ref) / np.linalg.norm(m_ref)) < 2e-2
+    assert float(np.linalg.norm(r0[8] - v_ref) / np.linalg.norm(v_ref)) < 4e-2

@@ -228,6 +228,44 @@ def test_attention_fwd_bwd(dev, dtype, B, H, Nq, Nk, D, causal, masked):
     assert relerr(dv, flat(vh.grad, Nk)) < tol
 
 
+def test_attention_at_benchmark_size_items_independent(dev):
+    """B H = 256, N = 1024, D = 64 (configs[1]'s self-attention, bf16).  Every (batch, head) is independent: items computed inside
+    the big batch equal the same items computed alone BITWISE (same kernels, same tile schedule), and one item matches the f32
+    reference.  Full-size buffers also put the operands at addresses small tensors never reach (the LDS-DMA path builds 64-bit
+    addresses from two 32-bit halves: a sign extension there faulted only for tensors above a 2 GiB boundary)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(21)
+    B, H, N, D = 32, 8, 1024, 64
+    C = H * D
+    pad = torch.empty(3 << 30, dtype=torch.uint8, device=dev)          # push the operands past a 2 GiB boundary
+    mk = lambda: (torch.randn(B * N, C, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    del pad
+    scale = D ** -0.5
+    def run(qq, kk, vv, dd, b):
+        o = torch.empty_like(qq); lse = torch.empty(b, H, N, dtype=torch.float32, device=dev); delta = torch.empty_like(lse)
+        dq, dk, dv = torch.empty_like(qq), torch.empty_like(kk), torch.empty_like(vv)
+        ops.attn_fwd(qq, kk, vv, o, lse, b, H, N, N, D, scale)
+        ops.attn_bwd(qq, kk, vv, o, lse, dd, delta, dq, dk, dv, b, H, N, N, D, scale)
+        return o, lse, dq, dk, dv
+    big = run(q, k, v, do, B)
+    for b in (0, 31):
+        sl = slice(b * N, (b + 1) * N)
+        one = run(q[sl].clone(), k[sl].clone(), v[sl].clone(), do[sl].clone(), 1)
+        for name, x, y in zip(("o", "lse", "dq", "dk", "dv"), big, one):
+            xx = x[b:b + 1] if name == "lse" else x[sl]
+            assert torch.equal(xx, y), (b, name)
+    def heads(x):
+        return x[:N].float().cpu().view(1, N, H, D).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    qh, kh, vh = heads(q), heads(k), heads(v)
+    oref, lseref = _attn_ref(qh, kh, vh, scale)
+    oref.backward(heads(do).detach())
+    flat = lambda x: x.permute(0, 2, 1, 3).reshape(N, C)
+    assert relerr(big[0][:N], flat(oref)) < TOL[torch.bfloat16] and relerr(big[1][:1], lseref) < 2e-3
+    assert relerr(big[2][:N], flat(qh.grad)) < 2 * TOL[torch.bfloat16]
+    assert relerr(big[3][:N], flat(kh.grad)) < 2 * TOL[torch.bfloat16] and relerr(big[4][:N], flat(vh.grad)) < 2 * TOL[torch.bfloat16]
+
+
 def test_attention_column_slices_and_rescale_branch(dev):
     """q/k/v as column slices of one fused [M,3C] buffer; one key row spiked so the running max jumps mid-stream."""
     ops, L = _ops()

@@ -15,4 +15,11 @@ python3 tools/rocprof_summary.py stats $(find $out/trace -name "*.db" | head -1)
 python3 tools/rocprof_summary.py pmc $(find $out/fetch -name "*.db" | head -1) $(find $out/write -name "*.db" | head -1) $out/${tag}_pmc_traffic.json
 head -12 $out/${tag}_kernel_stats.csv | cut -c1-160
 python3 -c "import json; d=json.load(open('$out/${tag}_pmc_traffic.json')); print(d['step_read_bytes'], d['step_write_bytes'], d['step_bytes'])"
-rm -rf $out/trace $out/fetch $out/write
+# decode leg (BASELINE configs[3]): kernel trace + the two HBM-side PMC passes of `bench.py --only-decode`
+rocprofv3 --kernel-trace --stats -d $out/dtrace -o dtrace -- python3 bench.py --only-decode --no-cpu-baseline > $out/dtrace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $out/dfetch -o dfetch -- python3 bench.py --only-decode --no-cpu-baseline > $out/dfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/dwrite -o dwrite -- python3 bench.py --only-decode --no-cpu-baseline > $out/dwrite.log 2>&1
+python3 tools/rocprof_summary.py stats $(find $out/dtrace -name "*.db" | head -1) $out/${tag}_decode_kernel_stats.csv
+python3 tools/rocprof_summary.py pmc_decode $(find $out/dfetch -name "*.db" | head -1) $(find $out/dwrite -name "*.db" | head -1) $out/${tag}_decode_pmc.json
+head -8 $out/${tag}_decode_kernel_stats.csv | cut -c1-160
+rm -rf $out/trace $out/fetch $out/write $out/dtrace $out/dfetch $out/dwrite

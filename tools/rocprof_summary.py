@@ -44,7 +44,7 @@ def stats(path, out):
             f.write(f'"{dm[n]}",{c},{t},{a:.1f},{100.0 * t / total:.2f},{mn},{mx}\n')
 
 
-def _per_step(path):
+def _per_step(path, mark="adamw_kernel"):
     db = sqlite3.connect(path)
     kd, ks, pmc = _tables(db)
     rows = db.execute(f"select d.start, s.kernel_name, d.dispatch_id, e.value from {pmc} e join {kd} d on e.event_id=d.event_id "
@@ -53,8 +53,9 @@ def _per_step(path):
     for st, n, did, v in rows:
         disp[(st, did, n)] = disp.get((st, did, n), 0) + v
     items = list(disp.items())
-    marks = [i for i, (k, _) in enumerate(items) if "adamw_kernel" in k[2]]
-    seg = items[marks[-2] + 1:marks[-1] + 1]          # one whole training step (optimizer kernel to optimizer kernel)
+    marks = [i for i, (k, _) in enumerate(items) if mark in k[2]]
+    # one whole unit of work: optimizer kernel to optimizer kernel (training step) / first kernel to first kernel (one decode)
+    seg = items[marks[-2] + 1:marks[-1] + 1] if mark == "adamw_kernel" else items[marks[-2]:marks[-1]]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for (_, _, n), v in seg:
         agg[n][0] += 1; agg[n][1] += v
@@ -81,10 +82,32 @@ def pmc(fetch_db, write_db, out):
         json.dump(res, f, indent=1)
 
 
+def pmc_decode(fetch_db, write_db, out):
+    """HBM-side bytes of ONE Encodec decode (`bench.py --only-decode`): the dispatches from one RVQ gather to the next."""
+    F, W = _per_step(fetch_db, "rvq_decode"), _per_step(write_db, "rvq_decode")
+    names = sorted(set(F) | set(W), key=lambda n: -(2 * F.get(n, [0, 0])[1] + W.get(n, [0, 0])[1]))
+    dm = _demangle(names)
+    kern = []
+    for n in names:
+        calls = max(F.get(n, [0, 0])[0], W.get(n, [0, 0])[0])
+        rd = 2.0 * F.get(n, [0, 0])[1] * 1024.0; wr = W.get(n, [0, 0])[1] * 1024.0
+        kern.append({"kernel": re.sub(r"\(anonymous namespace\)::", "", dm[n])[:160], "calls_per_decode": calls,
+                     "read_bytes": rd, "write_bytes": wr})
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --only-decode`; one decode of "
+                     "64 x 1024 frames (bf16); FETCH_SIZE doubled (gfx950), unit 1024 B",
+           "decode_read_bytes": sum(k["read_bytes"] for k in kern), "decode_write_bytes": sum(k["write_bytes"] for k in kern),
+           "kernels": kern[:24]}
+    res["decode_bytes"] = res["decode_read_bytes"] + res["decode_write_bytes"]
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "pmc_decode":
+        pmc_decode(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         raise SystemExit(__doc__)

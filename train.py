@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from prompt_tts_amd import checkpoint, launch, parallel
+from prompt_tts_amd import checkpoint, engine, launch, parallel
 from prompt_tts_amd.tts.dataloader import DeviceFeeder, SyntheticDataset, create_dataloader
 from prompt_tts_amd.tts.models import TTSSingleSpeaker
 
@@ -66,7 +66,8 @@ def main(args):
 
     torch.manual_seed(0)
     model = TTSSingleSpeaker(config, dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16).to(dev)
-    reducer = parallel.attach(model) if world > 1 else None
+    reducer = parallel.attach(model) if world > 1 else None           # PT_DP_SHARDED=1: reduce-scatter + sharded optimizer
+    sharded = reducer is not None and hasattr(reducer, "owned_ranges")
     ds = SyntheticDataset(args.synthetic, config["in_channels"], config["sample_size"], args.max_seq_length) if args.synthetic else None
     dataloader = create_dataloader(args.data_file, args.batch_size, args.max_seq_length, shuffle=True, dataset=ds,
                                    lazy=args.lazy_tar, num_workers=args.num_workers, rank=rank, world=world)
@@ -118,7 +119,10 @@ def main(args):
             if sync:
                 if reducer is not None:
                     reducer.finish()
-                st.adamw_step(ADAMW["lr"] * lam(opt_step), ADAMW["betas"], ADAMW["eps"], ADAMW["weight_decay"], 1.0)
+                if sharded:      # reduce-scatter done: AdamW on this rank's slices, all-gather of the new values
+                    engine.adamw_step_sharded(st, reducer, ADAMW["lr"] * lam(opt_step), ADAMW["betas"], ADAMW["eps"], ADAMW["weight_decay"], 1.0)
+                else:
+                    st.adamw_step(ADAMW["lr"] * lam(opt_step), ADAMW["betas"], ADAMW["eps"], ADAMW["weight_decay"], 1.0)
                 opt_step += 1; micro = 0
                 if opt_step % args.log_every == 0:
                     if world > 1:
@@ -135,6 +139,8 @@ def main(args):
             torch.distributed.all_gather_object(gathered, gen.get_state().cpu())
             gen_states = gathered
             torch.distributed.barrier()
+        if sharded and epoch % config["save_per_epochs"] == 0 and st.adam_m is not None:
+            reducer.allgather_published(st.adam_m); reducer.allgather_published(st.adam_v)   # the moments live on their owners
         if rank == 0 and epoch % config["save_per_epochs"] == 0:
             # same file names as the reference, which concatenates ckpt_dir and the name without a separator; optim_N.pt is a
             # torch.optim.AdamW state_dict (train.py:142).  Snapshots go to pinned host memory on a copy stream and are
