@@ -146,6 +146,18 @@ __device__ __forceinline__ void a2_dma16s(uint32_t voff, const void* sbase, char
 // base); image slot q = tid + 256 i is row q / NCH, physical chunk q % NCH, i.e. LOGICAL chunk (q % NCH) ^ sw(row): the
 // swizzle is applied to the per-lane source address.  Rows past the tensor's end re-read its last row (finite data; masked by
 // the caller): only the last, ragged tile takes that path.
+// 64 consecutive floats (one 64-row tile's LSE or delta slice) -> 256 bytes of LDS by ONE wave-instruction (4 bytes per lane);
+// rows past `limit` re-read the last row.
+__device__ __forceinline__ void a2_dma_f32x64(const float* base, int row0, int limit, char* lds, int lane) {
+  const uint64_t ta = (uint64_t)(base + row0);
+  const uint32_t ta_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta >> 32));
+  const uint32_t ta_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta);
+  const float* tile = reinterpret_cast<const float*>(((uint64_t)ta_hi << 32) | (uint64_t)ta_lo);
+  const int r = row0 + lane < limit ? lane : limit - 1 - row0;
+  const uint32_t a = (uint32_t)(uintptr_t)(a2_lptr*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)(r * 4)), "s"(tile), "s"(a) : "memory");
+}
+
 // NT = threads of the workgroup (256 or 512): the image's 64 NCH chunks are dealt out over NT threads; when the image has fewer
 // chunks than threads (D = 32 with 512 threads) only the first waves issue (wave-uniform predicate).
 template <int D, int NT = 256> struct A2Stage {

@@ -28,6 +28,18 @@ __device__ __forceinline__ f32x16_t a2_row_consts(const float* src, int row0, in
   return v;
 }
 
+// the same from the LDS copy of a 64-row tile's slice (row0 = 0 or 32): four broadcast ds_read_b128
+__device__ __forceinline__ f32x16_t a2_row_consts_lds(const char* lds, int row0, int h, float mul) {
+  f32x16_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(lds + (row0 + 8 * i + 4 * h) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * i + j] = -x[j] * mul;
+  }
+  return v;
+}
+
 // ---- dQ (and delta) ---------------------------------------------------------------------------------------------------
 template <int D, int WPS, int NW>
 __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_q_kernel(const AttnParams p) {
@@ -166,7 +178,8 @@ template <int D, int WPS, int NW>
 __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_kv_kernel(const AttnParams p) {
   using C = A2<D>;
   constexpr int KS = C::KS, DT = C::DT, TILE = C::TILE;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2 stages][Q image | dO image]
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2 stages][Q image | dO image | LSE (64 f32) | delta (64 f32)]
+  constexpr int STAGE = 2 * TILE + 512;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   int b, hd, blk;
@@ -189,10 +202,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_kv_kernel(const AttnPa
 
   A2Stage<D, 64 * NW> stQ, stDO;
   stQ.init(tid, p.ldq); stDO.init(tid, p.lddo);
-  if (nsteps > 0) {
-    stQ.issue(Q, qstart, p.Nq, smem, wave, tid);
-    stDO.issue(DO, qstart, p.Nq, smem + TILE, wave, tid);
-  }
+  // LSE / delta of a step's 64 queries travel with the tile (one 256-byte DMA piece each, waves 0 and 1): inside the loop there is
+  // then NO compiler-visible vector-memory load -- a global load of the row constants was waited for with vmcnt(0), i.e. together
+  // with the next tile's LDS-DMA issued just before it (in-order counter): 2 500 - 3 500 stalled cycles per 32-query block.
+  auto issue_step = [&](int q0_, char* stage) {
+    stQ.issue(Q, q0_, p.Nq, stage, wave, tid);
+    stDO.issue(DO, q0_, p.Nq, stage + TILE, wave, tid);
+    if (wave == 0) a2_dma_f32x64(LSE, q0_, p.Nq, stage + 2 * TILE, lane);
+    if (wave == 1) a2_dma_f32x64(DELTA, q0_, p.Nq, stage + 2 * TILE + 256, lane);
+  };
+  if (nsteps > 0) issue_step(qstart, smem);
 
   // register-resident B operands: column = key k0 + r, k = 16 ks + 8 h + j; K pre-multiplied by scale * log2(e)
   const float sl2 = p.scale * PT_LOG2E;
@@ -213,26 +232,20 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_kv_kernel(const AttnPa
   a2_dma_wait();
   __syncthreads();
 
-  // The row constants (-lse2, -delta of a block's 32 queries: the accumulators' initial values) are needed BEFORE the block's
-  // first MFMA: fetched at that point their L2 latency is exposed once per block.  They are therefore loaded one block ahead.
   const bool kmask = p.causal || (kblk + KB > nk);
-  f32x16_t s_nx = splat16(0.f), dp_nx = splat16(0.f);
-  if (nsteps > 0) {
-    const bool g0 = kmask || (qstart + 32 > p.Nq);
-    s_nx = a2_row_consts(LSE, qstart, h, p.Nq, PT_LOG2E, g0);
-    dp_nx = a2_row_consts(DELTA, qstart, h, p.Nq, 1.f, g0);
-  }
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1, qs0 = qstart + st * 64;
-    const char* qimg = smem + cur * 2 * TILE;
+    const char* qimg = smem + cur * STAGE;
     const char* doimg = qimg + TILE;
+    const char* lseimg = qimg + 2 * TILE;
     A2_KV_STAMP(8 * st + 1);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int qs = qs0 + 32 * hf;                       // this block's first query; image rows 32 hf ..
       if (qs < p.Nq) {                                    // wave-uniform
         const bool need_mask = kmask || (qs + 32 > p.Nq);
-        f32x16_t s = s_nx, dp = dp_nx;                    // rows = queries, column = this lane's key
+        // rows = queries, column = this lane's key; the accumulators start from the row constants -lse2 / -delta
+        f32x16_t s = a2_row_consts_lds(lseimg, 32 * hf, h, PT_LOG2E), dp = a2_row_consts_lds(lseimg + 256, 32 * hf, h, 1.f);
         {
           bf16x8_t qa[KS], da[KS];
 #pragma unroll
@@ -241,20 +254,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_kv_kernel(const AttnPa
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) { s = mma32(qa[ks], kf[ks], s); dp = mma32(da[ks], vf[ks], dp); }
         }
-        {                       // next block's row constants (in flight under this block's MFMAs)
-          const int qn = qs + 32;
-          if (qn < p.Nq) {
-            const bool gn = kmask || (qn + 32 > p.Nq);
-            s_nx = a2_row_consts(LSE, qn, h, p.Nq, PT_LOG2E, gn);
-            dp_nx = a2_row_consts(DELTA, qn, h, p.Nq, 1.f, gn);
-          }
-        }
         if (hf == 0) {          // next step's LDS-DMA in the shadow of the MFMAs just issued (block 0 of a step always runs)
           __builtin_amdgcn_sched_barrier(0);
-          if (st + 1 < nsteps) {
-            stQ.issue(Q, qs0 + 64, p.Nq, smem + (cur ^ 1) * 2 * TILE, wave, tid);
-            stDO.issue(DO, qs0 + 64, p.Nq, smem + (cur ^ 1) * 2 * TILE + TILE, wave, tid);
-          }
+          if (st + 1 < nsteps) issue_step(qs0 + 64, smem + (cur ^ 1) * STAGE);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (need_mask) {
@@ -309,16 +311,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_bwd_kv_kernel(const AttnPa
 // 2 leaves them 256).  NW = waves per workgroup: 8 waves share each K / V (Q / dO) tile, which halves the LDS-DMA pieces a wave
 // issues per tile (a piece costs 60 - 180 cycles of issue) and the L2 -> LDS traffic.  PT_ATTN_BWD_WPS / PT_ATTN_BWD_NW pick.
 template <int D, int WPS, int NW> int launch_bwd2(const AttnParams& p, hipStream_t s) {
-  const size_t lds = 2 * 2 * (size_t)A2<D>::TILE;
+  const size_t lds = 2 * 2 * (size_t)A2<D>::TILE, lds_kv = 2 * (2 * (size_t)A2<D>::TILE + 512);
   static const int a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_q_kernel<D, WPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  static const int a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kv_kernel<D, WPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kv_kernel<D, WPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   if (a1 != hipSuccess || a2 != hipSuccess) return PT_ERR_LAUNCH;
   constexpr int BLK = 32 * NW;
   const int64_t nq = (int64_t)((p.Nq + BLK - 1) / BLK) * p.H * p.B, nkv = (int64_t)((p.Nk + BLK - 1) / BLK) * p.H * p.B;
   if (nq >= (1ll << 31) || nkv >= (1ll << 31)) return PT_ERR_SHAPE;
   // dQ first: it also produces delta (rowsum(dO o O)) for the dK/dV kernel that follows on the same stream
   hipLaunchKernelGGL((attn2_bwd_q_kernel<D, WPS, NW>), dim3((unsigned)nq), dim3(64 * NW), lds, s, p);
-  hipLaunchKernelGGL((attn2_bwd_kv_kernel<D, WPS, NW>), dim3((unsigned)nkv), dim3(64 * NW), lds, s, p);
+  hipLaunchKernelGGL((attn2_bwd_kv_kernel<D, WPS, NW>), dim3((unsigned)nkv), dim3(64 * NW), lds_kv, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }

@@ -350,9 +350,9 @@ extern "C" int pt_attn_bwd(const pt_attn_desc* d, int dtype, pt_stream stream) {
   int st = pt_attn_fill_params(d, dtype, true, p);
   if (st) return st;
   hipStream_t s = (hipStream_t)stream;
-  // bf16: the second-generation kernels (attn2_bwd.hip) are selected by PT_ATTN_BWD_V2 (default set from measurements:
-  // tools/attn_probe.py, profiles/r03_attn_*)
-  static const int v2 = pt_env_int("PT_ATTN_V2", 1) && pt_env_int("PT_ATTN_BWD_V2", 0);
+  // bf16: the second-generation kernels (attn2_bwd.hip); PT_ATTN_V2=0 / PT_ATTN_BWD_V2=0 keep the round-2 kernels
+  // (self-attention N = 1024, B H = 256, D = 64: 305 vs 370 us, profiles/r03_attn_probe.log)
+  static const int v2 = pt_env_int("PT_ATTN_V2", 1) && pt_env_int("PT_ATTN_BWD_V2", 1);
   if (dtype == PT_BF16 && v2) return pt_attn2_bwd(p, (int)d->D, s);
 #define BWD(TT) \
   switch (d->D) { case 32: return launch_bwd<TT, 32>(p, s); case 64: return launch_bwd<TT, 64>(p, s); \
