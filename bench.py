@@ -473,7 +473,7 @@ def main():
             out["fp8_quantize"] = kern.get("pt_fp8_quantize")
         pmc = None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             if args.workload == "B" and args.dtype == "bf16" and not args.batch and os.path.exists(os.path.join(prof_dir, cand)):
                 with open(os.path.join(prof_dir, cand)) as f:
                     pmc = json.load(f)

@@ -55,7 +55,8 @@ def _per_step(path, mark="adamw_kernel"):
     items = list(disp.items())
     marks = [i for i, (k, _) in enumerate(items) if mark in k[2]]
     # one whole unit of work: optimizer kernel to optimizer kernel (training step) / first kernel to first kernel (one decode)
-    seg = items[marks[-2] + 1:marks[-1] + 1] if mark == "adamw_kernel" else items[marks[-2]:marks[-1]]
+    # (decode: the 2nd and 3rd RVQ gathers of the process are two consecutive iterations of bench.py's timing loop)
+    seg = items[marks[-2] + 1:marks[-1] + 1] if mark == "adamw_kernel" else items[marks[1]:marks[2]]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for (_, _, n), v in seg:
         agg[n][0] += 1; agg[n][1] += v
@@ -84,7 +85,7 @@ def pmc(fetch_db, write_db, out):
 
 def pmc_decode(fetch_db, write_db, out):
     """HBM-side bytes of ONE Encodec decode (`bench.py --only-decode`): the dispatches from one RVQ gather to the next."""
-    F, W = _per_step(fetch_db, "rvq_decode"), _per_step(write_db, "rvq_decode")
+    F, W = _per_step(fetch_db, "rvq_kernel<bf16_t"), _per_step(write_db, "rvq_kernel<bf16_t")
     names = sorted(set(F) | set(W), key=lambda n: -(2 * F.get(n, [0, 0])[1] + W.get(n, [0, 0])[1]))
     dm = _demangle(names)
     kern = []
