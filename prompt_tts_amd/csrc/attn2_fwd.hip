@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(cons
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = splat16(0.f);
   float m = 0.f, l = 0.f;                 // m: reference maximum of this lane's query (log2 units); l: this lane half's partial row sum
+
   const int qrow = q0 + r;
   a2_dma_wait();
   __syncthreads();
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(cons
         const bf16x8_t pf = a2_pack(s[kk >> 1], kk & 1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = mma32(va[kk][dt], pf, o[dt]);
+
       }
     }
     a2_dma_wait();            // this wave's pieces of the next tile have landed ...

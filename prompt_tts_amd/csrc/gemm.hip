@@ -23,6 +23,10 @@
 #ifndef PT_EPI_NT
 #define PT_EPI_NT -1       // tools/gemm_probe.py variant 7 / 8: force non-temporal epilogue stores on / off (-1: GemmParams::nt_store)
 #endif
+#ifndef PT_GEMM_ASM_DMA
+#define PT_GEMM_ASM_DMA 0       // experiment (make exp EXP_FLAGS=-DPT_GEMM_ASM_DMA=1): LDS-DMA of the two-stage kernels as inline asm;
+                                // measured neutral (round 3): unlike the attention rings, hipcc puts no alias wait into this loop
+#endif
 #ifndef PT_GEMM_ABLATE
 #define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores, 4 all three (launch floor)
 #endif
@@ -75,6 +79,16 @@ __device__ unsigned long long pt_trace[8];
 
 typedef __attribute__((address_space(1))) const void pt_gptr;
 typedef __attribute__((address_space(3))) void pt_lptr;
+
+// one LDS-DMA wave-instruction (1 KiB at the wave-uniform LDS address `lds`), builtin or asm form (see attn2.h: a2_dma16)
+__device__ __forceinline__ void pt_dma16(const char* src, char* lds) {
+#if PT_GEMM_ASM_DMA
+  const uint32_t a = (uint32_t)(uintptr_t)(pt_lptr*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory");
+#else
+  __builtin_amdgcn_global_load_lds((pt_gptr*)src, (pt_lptr*)lds, 16, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ void divmod(int x, int d, int shift, int& q, int& r) {
   if (shift >= 0) { q = x >> shift; r = x & (d - 1); }
@@ -682,11 +696,9 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
     }
     if (PT_GEMM_ABLATE == 2 || PT_GEMM_ABLATE == 4) return;
 #pragma unroll
-    for (int i = 0; i < Cfg::A_CHUNKS; ++i)
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pa[i], (pt_lptr*)(sa + (wbase + NTHREADS * i) * 16), 16, 0, 0);
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i) pt_dma16(pa[i], sa + (wbase + NTHREADS * i) * 16);
 #pragma unroll
-    for (int i = 0; i < Cfg::B_CHUNKS; ++i)
-      __builtin_amdgcn_global_load_lds((pt_gptr*)pb[i], (pt_lptr*)(sb + (wbase + NTHREADS * i) * 16), 16, 0, 0);
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i) pt_dma16(pb[i], sb + (wbase + NTHREADS * i) * 16);
   };
 
   auto compute = [&](int stg) {
@@ -721,8 +733,9 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
       }
       return;
     }
+    constexpr int NKS = (PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32;
 #pragma unroll
-    for (int ks = 0; ks < ((PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32); ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       Frag<T> fa[MI], fb[4];
       const int kb = ks * 32 + 8 * g;
 #pragma unroll
@@ -751,12 +764,14 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   if (NSTAGE == 2) {
     stage(kt_begin, 0);
     PT_STAMP(1);
+    if (PT_GEMM_ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
     PT_STAMP(2);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
       compute(cur);
+      if (PT_GEMM_ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
     }

@@ -172,3 +172,40 @@ def test_two_rank_sharded_optimizer_equals_the_replicated_one(dev):
     assert worst[0][0] < 5e-2, worst[:8]
     assert float(np.linalg.norm(r0[7] - m_ref) / np.linalg.norm(m_ref)) < 2e-2
     assert float(np.linalg.norm(r0[8] - v_ref) / np.linalg.norm(v_ref)) < 4e-2
+
+
+def test_range_optimizer_and_import_equal_the_full_step(dev):
+    """pt_adamw_step_range over a partition of the flat buffer (ragged, quad-aligned cuts that fall inside Conv1d k=3 rows and
+    GEGLU-interleaved weights) == pt_adamw_step over the whole buffer, BITWISE (master, moments, shadow); the values it publishes
+    into the gradient buffer, adopted by a third replica with pt_import_params_range, reproduce master and shadow."""
+    from prompt_tts_amd import ops
+    from prompt_tts_amd.tts.models import TTSSingleSpeaker
+    models = []
+    for _ in range(3):
+        torch.manual_seed(0)
+        models.append(TTSSingleSpeaker(_cfg(), dtype=torch.bfloat16).to(dev))
+    sa, sb, sc = (m.store for m in models)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    grad = torch.randn(sa.n_total, device=dev, generator=g) * 1e-2
+    hyp = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    n = sa.n_total
+    cuts = [0, 4 * (n // 13), 4 * (n // 7) + 4, 4 * (n // 5) + 12, n // 8 * 4 + 4 * 123457 % n // 4 * 4, n]
+    cuts = sorted(set(min(max(c, 0), n) for c in cuts))
+    for step in range(2):
+        for st in (sa, sb):
+            st.flat_g.copy_(grad * (step + 1))
+        gn = torch.zeros(1, device=dev); ops.sumsq(sa.flat_g, gn)
+        sa.adamw_step(hyp["lr"], hyp["betas"], hyp["eps"], hyp["weight_decay"], 1.0, gnorm_sq=gn.clone())
+        if sb.adam_m is None:
+            sb.adam_m = torch.zeros_like(sb.flat_p); sb.adam_v = torch.zeros_like(sb.flat_p)
+        sb.step_count += 1
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ops.adamw_step_range(sb.flat_p, sb.flat_g, sb.adam_m, sb.adam_v, sb.shadow, sb.seg_dev, sb.n_seg, lo, hi, gn, 1.0,
+                                 hyp["lr"], hyp["betas"][0], hyp["betas"][1], hyp["eps"], hyp["weight_decay"], sb.step_count, True)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ops.import_params_range(sc.flat_p, sb.flat_g, sc.shadow, sc.seg_dev, sc.n_seg, lo, hi)
+        torch.cuda.synchronize()
+        for name in ("flat_p", "adam_m", "adam_v", "shadow"):
+            assert torch.equal(getattr(sa, name), getattr(sb, name)), (step, name)
+        assert torch.equal(sa.flat_p, sc.flat_p) and torch.equal(sa.shadow, sc.shadow), step
+    assert float((sa.flat_p - models[0].store.flat_p).abs().sum()) == 0.0 and len(cuts) >= 5

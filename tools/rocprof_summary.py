@@ -85,7 +85,7 @@ def pmc(fetch_db, write_db, out):
 
 def pmc_decode(fetch_db, write_db, out):
     """HBM-side bytes of ONE Encodec decode (`bench.py --only-decode`): the dispatches from one RVQ gather to the next."""
-    F, W = _per_step(fetch_db, "rvq_kernel<bf16_t"), _per_step(write_db, "rvq_kernel<bf16_t")
+    F, W = _per_step(fetch_db, "rvq_kernelI6bf16_t"), _per_step(write_db, "rvq_kernelI6bf16_t")
     names = sorted(set(F) | set(W), key=lambda n: -(2 * F.get(n, [0, 0])[1] + W.get(n, [0, 0])[1]))
     dm = _demangle(names)
     kern = []
