@@ -338,7 +338,7 @@ int pt_attn2_bwd(const AttnParams& p, int D, hipStream_t s) {
   switch (D) {
     case 32: return nw == 8 ? launch_bwd2<32, 2, 8>(p, s) : launch_bwd2<32, 3, 4>(p, s);
     case 64: return nw == 8 ? launch_bwd2<64, 2, 8>(p, s) : launch_bwd2<64, 2, 4>(p, s);
-    case 128: return nw == 8 ? launch_bwd2<128, 2, 8>(p, s) : launch_bwd2<128, 2, 4>(p, s);
+    case 128: return launch_bwd2<128, 1, 4>(p, s);      // one wave per SIMD: 512 registers (at 256 the kernels spill 6 - 30 of them)
     default: return PT_ERR_SHAPE;
   }
 }

@@ -13,7 +13,7 @@ namespace {
 constexpr float A2_RESCALE_THR = 8.f;    // log2 units: probabilities stay below 2^8 between two refreshes of the maximum
 
 template <int D>
-__global__ __launch_bounds__(256, (D == 128 ? 2 : 3)) void attn2_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (D == 128 ? 1 : 3)) void attn2_fwd_kernel(const AttnParams p) {
   using C = A2<D>;
   constexpr int KS = C::KS, DT = C::DT, TILE = C::TILE;
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2 stages][K image | V image]

@@ -10,6 +10,9 @@ from prompt_tts_amd import ops  # noqa: E402
 
 SHAPES = [("self N1024", 32, 8, 1024, 1024, 64), ("self N512", 32, 8, 512, 512, 64), ("cross 1024x256", 32, 8, 1024, 256, 64),
           ("cross 512x256", 32, 8, 512, 256, 64), ("text 256x256", 32, 8, 256, 256, 64)]
+if os.environ.get("PT_PROBE_OTHER_D") == "1":      # configs[4] (D = 128, N = 2048) and configs[0] (D = 32) shapes
+    SHAPES = [("E self N2048 D128", 8, 8, 2048, 2048, 128), ("E cross 2048x256 D128", 8, 8, 2048, 256, 128),
+              ("E text 256 D64 H16", 8, 16, 256, 256, 64), ("A self N1024 D32", 4, 8, 1024, 1024, 32), ("A cross D32", 4, 8, 1024, 256, 32)]
 
 
 def t(fn, iters=20):
