@@ -101,6 +101,35 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, float*
         store4<T>(shadow + sg.shadow_offset + (sg.layout == 2 ? geglu_shadow_index(sg, local) : local), pv[0], pv[1], pv[2], pv[3]);
         continue;
       }
+      if (sg.layout == 1 && (sg.cin & 3) == 0 && local + 3 < sg.numel && i + 3 < hi) {
+        // conv k=3 quad: 4 consecutive input channels of one (output channel, tap).  g, m, v (tap-major, like the shadow) move as
+        // 16-byte vectors; only the master, which keeps the reference's (Cout, Cin, 3) order, is touched element-wise (stride 3)
+        const int64_t per_co = (int64_t)sg.cin * 3;
+        const int64_t co = local / per_co; const int rem = (int)(local - co * per_co);
+        const int tap = rem / sg.cin, ci = rem - tap * sg.cin;
+        float* pp = p + sg.offset + co * per_co + (int64_t)ci * 3 + tap;
+        f32x4_t pv = {pp[0], pp[3], pp[6], pp[9]};
+        if (IMPORT && !sg.frozen) {
+          pv = *reinterpret_cast<const f32x4_t*>(g + i);
+          pp[0] = pv[0]; pp[3] = pv[1]; pp[6] = pv[2]; pp[9] = pv[3];
+        }
+        if (UPDATE && !sg.frozen) {
+          const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i);
+          f32x4_t mv = *reinterpret_cast<const f32x4_t*>(m + i), vv = *reinterpret_cast<const f32x4_t*>(v + i);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * clip;
+            mv[e] = b1 * mv[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pv[e] = pv[e] * decay - step * (mv[e] / (sqrtf(vv[e]) * rbc2 + eps));
+          }
+          *reinterpret_cast<f32x4_t*>(m + i) = mv; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+          pp[0] = pv[0]; pp[3] = pv[1]; pp[6] = pv[2]; pp[9] = pv[3];
+        }
+        if (UPDATE && publish) *reinterpret_cast<f32x4_t*>(g + i) = pv;
+        store4<T>(shadow + sg.shadow_offset + (co * 3 + tap) * sg.cin_pad + ci, pv[0], pv[1], pv[2], pv[3]);
+        continue;
+      }
       for (int e = 0; e < 4 && local + e < sg.numel && i + e < hi; ++e) {
         const int64_t ge_i = i + e;                  // position in the gradient buffer
         int64_t le = local + e;                      // element of the tensor in MASTER order
