@@ -197,7 +197,9 @@ def decode_time(dev, dtype, prompts, T, iters):
     from prompt_tts_amd.encodec import EncodecDecoder
     dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=dtype)
     codes = torch.randint(0, 1024, (prompts, 8, T), generator=torch.Generator().manual_seed(7)).to(dev)
-    dec.decode(codes); torch.cuda.synchronize()
+    for _ in range(2):                       # the first calls pay for ~20 GB of fresh allocations (f32 activations)
+        dec.decode(codes)
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -276,9 +278,10 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
            "weights": "seeded random (no checkpoint offline)"}
     # the same workload at the REFERENCE's precision (decode_codec.py decodes in fp32), and what each dtype costs in accuracy
-    ms32 = decode_time(dev, torch.float32, prompts, T, max(2, iters // 2))
+    ms32 = decode_time(dev, torch.float32, prompts, T, max(3, iters // 2))
     out["f32"] = {"value": audio_s / (ms32 * 1e-3), "unit": "audio-s/s", "ms_per_batch": ms32, "dtype": "f32",
-                  "note": "parity mode: exact-f32 MFMA GEMMs, f32 activations; meets the 1e-3 bound (see parity)"}
+                  "note": "f32 activations and accumulation, products as bf16 x 3 splits on the bf16 MFMA (error ~2^-16 per product), "
+                          "persistent LSTM with hi / lo weight fragments in registers; meets the 1e-3 bound (see parity)"}
     if cpu:
         out["parity"] = decode_parity(dev)
         out["cpu_baseline"] = decode_cpu_baseline()

@@ -105,7 +105,11 @@ typedef struct pt_gemm_desc {
   float* arow_sum;               /* PT_OUT_F32_ATOMIC only, or NULL: arow_sum[m] += alpha * sum_k VA(m,k) for m < arow_n -- the bias
                                     gradient (column sums of dy) rides on the wgrad GEMM as one extra all-ones MFMA column, in
                                     the workgroups of the first tile column; replicated destination like pt_colsum           */
-  int64_t arow_n; int64_t arow_stride; int32_t arow_rep; int32_t _pad2;
+  int64_t arow_n; int64_t arow_stride; int32_t arow_rep;
+  int32_t f32_x3;                /* PT_F32 forward GEMMs (plain / conv operands, store epilogue): != 0 = products as a bf16 x 3 split
+                                    (3 bf16 MFMAs, error ~2^-16 per product) instead of the exact f32 MFMA (8 instructions at 1/16
+                                    of the bf16 rate).  For f32 INFERENCE that has to match fp32 to 1e-3 (Encodec decode,
+                                    decode_codec.py:12-16); the training parity mode leaves it 0.                              */
   int64_t geglu_rows;            /* pt_wgrad_group only, or 0: F > 0 = the M = 2F rows of this weight gradient are in the
                                     interleaved order of act = 2 (A = d(projection) as written by act = 3); C and arow_sum are
                                     written in the ORIGINAL row order                                                       */
@@ -328,6 +332,7 @@ typedef struct pt_rowconv_desc {
   const float* bias; int32_t N; int32_t act;   /* act: 0 none, 1 ELU                                        */
   void* y; int64_t ldy; int32_t y_f32;
   int32_t stride;                  /* PT_MAP_STRIDED_REFLECT: x has stride * n_rows rows per batch item               */
+  int32_t f32_x3; int32_t _pad;    /* PT_F32: != 0 = bf16 x 3 products, as pt_gemm_desc.f32_x3                              */
 } pt_rowconv_desc;
 int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream);
 

@@ -39,7 +39,7 @@ class pt_gemm_desc(C.Structure):
                 ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
                 ("C2", C.c_void_p), ("ldc2", C.c_int64),
                 ("arow_sum", C.c_void_p), ("arow_n", C.c_int64), ("arow_stride", C.c_int64), ("arow_rep", C.c_int32),
-                ("_pad2", C.c_int32), ("geglu_rows", C.c_int64)]
+                ("f32_x3", C.c_int32), ("geglu_rows", C.c_int64)]
 
 
 class pt_attn_desc(C.Structure):
@@ -57,7 +57,7 @@ class pt_rowconv_desc(C.Structure):
                 ("taps", C.c_int32), ("rowmap", C.c_int32), ("elu_x", C.c_int32), ("x2", C.c_void_p), ("ldx2", C.c_int64),
                 ("cin2", C.c_int32), ("elu_x2", C.c_int32), ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
                 ("N", C.c_int32), ("act", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int64), ("y_f32", C.c_int32),
-                ("stride", C.c_int32)]
+                ("stride", C.c_int32), ("f32_x3", C.c_int32), ("_pad", C.c_int32)]
 
 
 class pt_lstm2_desc(C.Structure):

@@ -1,6 +1,7 @@
 // Encodec decoder kernels that do not fit the 128x128 GEMM: RVQ gather-sum, row-streaming conv for few output
 // channels (the 24 kHz end of the SEANet decoder: 16..64 channels, HBM-bound), and the 2-layer LSTM recurrence.
 #include <stdlib.h>
+#include <type_traits>
 #include "mma.h"
 
 namespace {
@@ -63,6 +64,7 @@ struct RowConvParams {
   const char* x2; int64_t ldx2; int cin2, elu_x2;
   const char* w; int64_t ldw; const float* bias; int N, act;
   char* y; int64_t ldy; int y_f32;
+  int x3;                       // T = float: bf16 x 3 products (mma.h)
 };
 
 __device__ __forceinline__ float elu_f(float v) { return v < 0.f ? (__expf(v) - 1.f) : v; }
@@ -77,18 +79,23 @@ template <> __device__ __forceinline__ void frag_elu<float>(Frag<float>& f) {
   for (int j = 0; j < 8; ++j) f.v[j] = elu_f(f.v[j]);
 }
 
-template <typename T, int NT, int KS>
+// X3 (T = float only): weights are split into bf16 hi / lo fragments once, every activation fragment on load, and a product is
+// three bf16 MFMAs instead of eight exact-f32 ones (the f32 kernels were MFMA-issue bound, not HBM bound).
+template <typename T, int NT, int KS, bool X3 = false>
 __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   // weights -> registers, once: B-operand fragment (col = output channel li of tile nt, k = 32*ks + 8g + j)
-  Frag<T> wf[NT][KS];
+  using WF = typename std::conditional<X3, FragX3, Frag<T>>::type;
+  WF wf[NT][KS];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = 16 * nt + li;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (n < p.N) frag_load_global(wf[nt][ks], reinterpret_cast<const T*>(p.w) + (int64_t)n * p.ldw + 32 * ks + 8 * g);
-      else frag_zero(wf[nt][ks]);
+      Frag<T> w;
+      if (n < p.N) frag_load_global(w, reinterpret_cast<const T*>(p.w) + (int64_t)n * p.ldw + 32 * ks + 8 * g);
+      else frag_zero(w);
+      if constexpr (X3) wf[nt][ks] = split_x3(w); else wf[nt][ks] = w;
     }
   }
   const int K1 = p.taps * p.cin;
@@ -126,8 +133,14 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
         }
         if (!have) frag_zero(fa);
         if (elu) frag_elu<T>(fa);
+        if constexpr (X3) {
+          const FragX3 xa = split_x3(fa);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mma16(acc[rt][nt], wf[nt][ks], fa);        // D[row = n][col = m]
+          for (int nt = 0; nt < NT; ++nt) mma16x3(acc[rt][nt], wf[nt][ks], xa);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mma16(acc[rt][nt], wf[nt][ks], fa);      // D[row = n][col = m]
+        }
       }
     }
     // epilogue: lane holds, for row m = r0 + 16rt + li, channels n = 16nt + 4g + r
@@ -163,6 +176,13 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
 template <typename T, int NT, int KS> int launch_rowconv(const RowConvParams& p, hipStream_t s) {
   int64_t blocks = (p.M + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if constexpr (std::is_same<T, float>::value) {
+    if (p.x3) {
+      hipLaunchKernelGGL((rowconv_kernel<T, NT, KS, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      PT_LAUNCH_CHECK();
+      return PT_OK;
+    }
+  }
   hipLaunchKernelGGL((rowconv_kernel<T, NT, KS>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
@@ -441,6 +461,181 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
     if (active && layer == 1 && bvalid) {
       const float v = hn + xskip;
       p.out_elu[oi1] = from_f32<bf16_t>(v < 0.f ? (__expf(v) - 1.f) : v);
+    }
+  }
+}
+
+// ---- persistent 2-layer LSTM, f32-class arithmetic (PT_F32: the reference's precision, decode_codec.py:12-16) ------------------
+// Same plan as lstm2_persist_kernel -- clusters of 16 batch rows x 64 workgroups, workgroup u owns hidden units 8u .. 8u+7 of both
+// layers, one data-tagged hand-off per tick -- with every product carried as a bf16 x 3 split:
+//     W = Whi + Wlo,  h = hhi + hlo  (bf16 each)      W h  ~  Whi hhi + Whi hlo + Wlo hhi      (error ~2^-16 per product)
+// which costs 3 bf16 MFMAs where the exact-f32 MFMA costs 16.  The 32 x 1536 weights of a workgroup do not fit LDS as hi + lo
+// (192 KiB), but they fit the REGISTER file: the workgroup's four waves split the reduction, and a wave keeps the B fragments
+// of its k-steps for the whole kernel (24 fragments x {hi, lo} = 192 registers per lane; one wave per SIMD may use 512) -- the
+// MFMAs read no LDS at all.  A granule is 16 bytes {hi pair, lo pair, tag, tag}, written by ONE sc1 16-byte store (observed
+// untorn on gfx950; the two tag words catch a torn 8-byte half); a b128 load returns exactly one granule = two hidden units.
+// Input gates, skip connection and output are f32.  The per-step kernels took 17.8 us per tick (T + 1 launches re-reading
+// 12 MiB of f32 weights through L2); see DESIGN.md for the measured tick of this form.
+struct LstmPersist3 {
+  int B, T, b_base, clusters;
+  const float* x; const float* xg0; const float* whh0; const float* wcat1; const float* bias1;
+  float* out_elu;
+  u32x4_t* gx;              // granules [2 parity][2 layer][clusters * 16 rows][256 unit pairs]; zeroed by the launch function
+  unsigned* err; int spin_limit; int fault_slice;
+};
+
+__device__ __forceinline__ void split_bf16x8(const float* w, Frag<bf16_t>& hi, Frag<bf16_t>& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)w[j];
+    hi.v[j] = h; lo.v[j] = (__bf16)(w[j] - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersist3 p) {
+  __shared__ float red[4 * 4 * 4 * 64];
+  __shared__ int abort_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x / LP_SLICES, u = blockIdx.x % LP_SLICES;
+  const int rows = p.clusters * 16;
+  if (tid == 0) abort_flag = 0;
+
+  // ---- resident weights as register B fragments: column lc = 16 tl + li (gate 2 tl + (li >> 3), unit li & 7), k = 32 ks + 8 g + j;
+  //      this wave's k-steps: layer 0: 4 wave + k; layer 1: 4 wave + k (h0 part) and 16 + 4 wave + k (h1 part) ----
+  Frag<bf16_t> w0h[4][2], w0l[4][2], w1ah[4][2], w1al[4][2], w1bh[4][2], w1bl[4][2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int lc = 16 * tl + li;
+      const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
+      const int k0 = 32 * (4 * wave + k) + 8 * g;
+      split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
+      split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
+      split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], w1bl[k][tl]);
+    }
+  // ---- gate-math role of this thread: (layer, batch row, unit) ----
+  const int layer = tid >> 7, b = (tid >> 3) & 15, jj = tid & 7;
+  const int bglob = p.b_base + 16 * c + b;
+  const bool bvalid = bglob < p.B;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (layer == 1) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + LP_UNITS * u + jj];
+  }
+  float cstate = 0.f;
+  const int gbytes = 2 * 2 * rows * 256 * 16;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, gbytes, 0x00020000);
+  __syncthreads();
+
+  for (int s = 0; s <= p.T; ++s) {
+    const bool l0 = s < p.T, l1 = s >= 1;
+    float xg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (layer == 0 && l0 && bvalid) {
+      const float* xp = p.xg0 + ((int64_t)bglob * p.T + s) * (4 * LP_H) + LP_UNITS * u + jj;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) xg[gi] = xp[gi * LP_H];
+    }
+    float xskip = 0.f;
+    const int64_t oi1 = ((int64_t)bglob * p.T + (s - 1)) * LP_H + LP_UNITS * u + jj;
+    if (layer == 1 && l1 && bvalid) xskip = p.x[oi1];
+
+    f32x4_t acc[4];                                         // [layer * 2 + tile]: D[row = batch][col = local gate column]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (s >= 1) {
+      // h0_{s-1} (and h1_{s-2}): row li of the cluster, this wave's k-steps; the 8 units of a fragment are 4 granules = 64
+      // contiguous bytes; every tag word must read s
+      const int par = (s - 1) & 1;
+      const unsigned want = (unsigned)s;
+      const int voff0 = (((par * 2 + 0) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 16;
+      const int voff1 = (((par * 2 + 1) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 16;
+      const bool need1 = s >= 2;
+      u32x4_t v0[16], v1[16];
+      int spin = 0;
+      bool aborted = false;
+      for (;;) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v0[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 256 * k + 16 * i, 0, 16);
+        if (need1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v1[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 256 * k + 16 * i, 0, 16);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ok &= (v0[i][2] == want) & (v0[i][3] == want);
+        if (need1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ok &= (v1[i][2] == want) & (v1[i][3] == want);
+        }
+        if (__all(ok)) break;
+        if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          if (lane == 0) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); abort_flag = 1; }
+          aborted = true;
+          break;
+        }
+      }
+      if (!aborted) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          Frag<bf16_t> a0h, a0l, a1h, a1l;
+          const u32x4_t h0 = {v0[4 * k][0], v0[4 * k + 1][0], v0[4 * k + 2][0], v0[4 * k + 3][0]};
+          const u32x4_t o0 = {v0[4 * k][1], v0[4 * k + 1][1], v0[4 * k + 2][1], v0[4 * k + 3][1]};
+          a0h.v = __builtin_bit_cast(bf16x8_t, h0); a0l.v = __builtin_bit_cast(bf16x8_t, o0);
+          const u32x4_t h1 = {v1[4 * k][0], v1[4 * k + 1][0], v1[4 * k + 2][0], v1[4 * k + 3][0]};
+          const u32x4_t o1 = {v1[4 * k][1], v1[4 * k + 1][1], v1[4 * k + 2][1], v1[4 * k + 3][1]};
+          a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
+#pragma unroll
+          for (int tl = 0; tl < 2; ++tl) {
+            if (l0) { mma16(acc[tl], a0h, w0h[k][tl]); mma16(acc[tl], a0h, w0l[k][tl]); mma16(acc[tl], a0l, w0h[k][tl]); }
+            mma16(acc[2 + tl], a0h, w1ah[k][tl]); mma16(acc[2 + tl], a0h, w1al[k][tl]); mma16(acc[2 + tl], a0l, w1ah[k][tl]);
+            if (need1) { mma16(acc[2 + tl], a1h, w1bh[k][tl]); mma16(acc[2 + tl], a1h, w1bl[k][tl]); mma16(acc[2 + tl], a1l, w1bh[k][tl]); }
+          }
+        }
+      }
+    }
+    __syncthreads();                                        // the gate math of the previous tick has finished reading `red`
+    if (abort_flag) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 4 + i) * 4 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+    const bool active = layer == 0 ? l0 : l1;
+    float hn = 0.f;
+    if (active) {
+      float pre[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int tile = layer * 2 + (gi >> 1), src_lane = ((gi & 1) * 8 + jj) + 16 * (b >> 2), r = b & 3;
+        float v = layer == 0 ? xg[gi] : bias[gi];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((w * 4 + tile) * 4 + r) * 64 + src_lane];
+        pre[gi] = v;
+      }
+      const float ig = 1.f / (1.f + expf(-pre[0])), fg = 1.f / (1.f + expf(-pre[1])), gg = tanhf(pre[2]), og = 1.f / (1.f + expf(-pre[3]));
+      cstate = fg * cstate + ig * gg;
+      hn = og * tanhf(cstate);
+    }
+    if (s < p.T) {
+      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
+      const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
+      const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
+      const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
+      if ((jj & 1) == 0) {
+        const unsigned tag = (unsigned)(s + 1) + ((int)blockIdx.x == p.fault_slice ? 0x40000000u : 0u);
+        const u32x4_t gran = {hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + 16 * c + b)) * 256 + (LP_UNITS * u + jj) / 2;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+      }
+    }
+    if (active && layer == 1 && bvalid) {
+      const float v = hn + xskip;
+      p.out_elu[oi1] = v < 0.f ? (expf(v) - 1.f) : v;
     }
   }
 }
@@ -902,6 +1097,7 @@ extern "C" int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream)
   p.x2 = (const char*)d->x2; p.ldx2 = d->ldx2; p.cin2 = d->x2 ? d->cin2 : 0; p.elu_x2 = d->elu_x2;
   p.w = (const char*)d->w; p.ldw = d->ldw; p.bias = d->bias; p.N = d->N; p.act = d->act;
   p.y = (char*)d->y; p.ldy = d->ldy; p.y_f32 = d->y_f32;
+  p.x3 = (dtype == PT_F32 && d->f32_x3) ? 1 : 0;
   const int nt = d->N <= 16 ? 1 : (d->N <= 32 ? 2 : 4), ks = (int)(d->ldw / 32);
   hipStream_t s = (hipStream_t)stream;
   return dtype == PT_F32 ? dispatch_rowconv<float>(p, nt, ks, s) : dispatch_rowconv<bf16_t>(p, nt, ks, s);
@@ -953,6 +1149,31 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 8), s) != hipSuccess) return PT_ERR_LAUNCH;
       hipLaunchKernelGGL(lstm2_persist_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
+      PT_LAUNCH_CHECK();
+    }
+    return PT_OK;
+  }
+  // f32 (the reference's precision): the same persistent plan with bf16 x 3 products and register-resident hi / lo weights
+  static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
+  const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
+  if (persist && persist3 && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
+    const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
+    const int rows_per_launch = 16 * max_clusters;
+    for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
+      LstmPersist3 q;
+      q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
+      const int64_t nb = d->B - b0 < rows_per_launch ? d->B - b0 : rows_per_launch;
+      q.clusters = (int)((nb + 15) / 16);
+      q.x = (const float*)d->x; q.xg0 = (const float*)d->xg0; q.whh0 = (const float*)d->whh0; q.wcat1 = (const float*)d->wcat1;
+      q.bias1 = d->bias1; q.out_elu = (float*)d->out_elu;
+      q.err = status;
+      q.gx = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(d->h0_seq) + 256);
+      q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
+      q.fault_slice = e_fault ? atoi(e_fault) : -1;
+      const bool first = b0 == 0;
+      char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
+      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
+      hipLaunchKernelGGL(lstm2_persist3_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
       PT_LAUNCH_CHECK();
     }
     return PT_OK;

@@ -61,6 +61,7 @@ struct GemmParams {
   int64_t geglu_rows;          // pt_wgrad_group: > 0 = the GEMM's rows are GEGLU-interleaved weight rows (F = geglu_rows)
   const float* scale_a; const float* scale_b;   // pt_gemm_fp8: device-resident dequantisation factors of the two operands
   int nt_store;                // epilogue rows as non-temporal stores (store_out)
+  int x3;                      // f32 forward GEMMs: bf16 x 3 products (mma.h) instead of the exact f32 MFMA
 };
 struct f8_t { uint8_t bits; };   // one fp8 operand element (e4m3 or e5m2): addressing only
 
@@ -734,6 +735,24 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
       return;
     }
     constexpr int NKS = (PT_GEMM_ABLATE == 1 || PT_GEMM_ABLATE == 4) ? 0 : BK / 32;
+    if constexpr (std::is_same<T, float>::value && !TA && !TB && !ATOMIC && F8 == 0) {
+      if (p.x3) {                                            // wave-uniform: f32 operands, bf16 x 3 products
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int kb = ks * 32 + 8 * g;
+          FragX3 xa[MI], xb[4];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) { Frag<T> f; frag_load_k(f, sa, wm * WM + 16 * i + li, kb); xa[i] = split_x3(f); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { Frag<T> f; frag_load_k(f, sb, wn * 64 + 16 * j + li, kb); xb[j] = split_x3(f); }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16x3(acc[i][j], xb[j], xa[i]);   // D[row = n][col = m]
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       Frag<T> fa[MI], fb[4];
@@ -1366,6 +1385,7 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
   p.geglu_rows = d->geglu_rows;
   p.scale_a = p.scale_b = nullptr;
   { static const int nt = pt_env_int("PT_GEMM_NT", 0); p.nt_store = nt; }
+  p.x3 = (dtype == PT_F32 && d->f32_x3) ? 1 : 0;
   if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
   if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
   if (d->act >= 2) {

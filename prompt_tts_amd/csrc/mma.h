@@ -26,6 +26,27 @@ __device__ __forceinline__ void mma16(f32x4_t& acc, const Frag<float>& a, const 
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 
+// ---- bf16 x 3: f32 operands, f32-class products on the bf16 MFMA ----------------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi);  a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi  (the dropped a_lo b_lo term and the
+// rounding of lo are ~2^-17 relative).  Three v_mfma_f32_16x16x32_bf16 (48 cycles) where the exact form takes eight
+// v_mfma_f32_16x16x4_f32 (256 cycles).  Used where the reference's fp32 arithmetic has to be matched to 1e-3, not bit for bit
+// (Encodec decode at f32: decode_codec.py:12-16); the training parity mode keeps the exact f32 MFMA.
+struct FragX3 { bf16x8_t hi, lo; };
+__device__ __forceinline__ FragX3 split_x3(const Frag<float>& f) {
+  FragX3 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)f.v[j];
+    r.hi[j] = h; r.lo[j] = (__bf16)(f.v[j] - (float)h);
+  }
+  return r;
+}
+__device__ __forceinline__ void mma16x3(f32x4_t& acc, const FragX3& a, const FragX3& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);     // small terms first
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
 // pack 8 f32 (lane-local) into a fragment
 __device__ __forceinline__ void frag_from_f32(Frag<bf16_t>& f, const float* x) {
 #pragma unroll

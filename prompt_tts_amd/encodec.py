@@ -111,6 +111,9 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None)
     return ze, st
 
 
+# f32 decode: products as a bf16 x 3 split on the bf16 MFMA (error ~2^-16 per product; the decode meets the 1e-3 bound with a
+# wide margin) instead of the exact f32 MFMA, which runs at 1/16 of the bf16 rate.  PT_ENCODEC_F32_X3=0: exact f32 everywhere.
+F32_X3 = __import__("os").environ.get("PT_ENCODEC_F32_X3", "1") != "0"
 FUSED_TAIL = __import__("os").environ.get("PT_ENCODEC_FUSED_TAIL", "1") != "0"
 FUSED_STAGES = __import__("os").environ.get("PT_ENCODEC_FUSED_STAGES", "1") != "0"
 
@@ -123,6 +126,7 @@ class EncodecDecoder:
         if missing:
             raise KeyError(f"missing decoder weights: {missing[:4]}...")
         self.device, self.dtype, self.pt = torch.device(device), dtype, ops._DT[dtype]
+        self.x3 = F32_X3 and dtype == torch.float32
         W = {k: v.detach().float().cpu() for k, v in weights.items()}
         d = lambda t: t.to(self.device, dtype).contiguous()
         f = lambda t: t.to(self.device, torch.float32).contiguous()
@@ -166,6 +170,7 @@ class EncodecDecoder:
             d.x2, d.ldx2, d.cin2, d.elu_x2 = x2.data_ptr(), x2.stride(0), cin2, elu_x2
         d.w, d.ldw, d.bias, d.N, d.act = w.data_ptr(), w.stride(0), bias.data_ptr(), N, act
         d.y, d.ldy, d.y_f32 = y.data_ptr(), y.stride(0), int(y_f32)
+        d.f32_x3 = int(getattr(self, "x3", False))
         check(lib.pt_rowconv(C.byref(d), self.pt, ops._stream()), "pt_rowconv")
 
     def _empty(self, rows, cols, dtype=None):
@@ -193,9 +198,9 @@ class EncodecDecoder:
         check(lib.pt_rvq_decode(codes.data_ptr(), self.codebooks.data_ptr(), e0.data_ptr(), B, n_q, T, 1024, 128, pt,
                                 ops._stream()), "pt_rvq_decode")
         y0 = self._empty(M, 512)
-        ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0), y0, pt, bias=self.b0)
+        ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0), y0, pt, bias=self.b0, x3=self.x3)
         xg0 = self._empty(M, 2048)
-        ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
+        ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0, x3=self.x3)
         ze, lstm_status = run_lstm2(B, T, y0, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status())
         xe, n = ze, T                     # xe = ELU(stage input), n = rows per batch item
         fuse_tail = (self.dtype == torch.bfloat16 and FUSED_TAIL and
@@ -229,7 +234,7 @@ class EncodecDecoder:
             x1e = None
             if self.dtype == torch.bfloat16 and FUSED_STAGES and cout == 128 and not st["small_up"] and n_out >= 3:
                 # transposed conv as a GEMM (its 640 x 512 weights do not fit a CU), then the whole residual block in one launch
-                ops.gemm(Min, r * cout, 2 * cin, ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2), ops.plain(st["wt"]), x1, pt, bias=st["bt"])
+                ops.gemm(Min, r * cout, 2 * cin, ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2), ops.plain(st["wt"]), x1, pt, bias=st["bt"], x3=self.x3)
                 oute = self._empty(Mout, cout)
                 sd = L.pt_encodec_stage_desc()
                 sd.B, sd.n, sd.cin, sd.cout, sd.r = B, n_out, cout, cout, 1
@@ -244,7 +249,7 @@ class EncodecDecoder:
             else:
                 x1e = self._empty(Min, r * cout)
                 ops.gemm(Min, r * cout, 2 * cin, ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2), ops.plain(st["wt"]), x1, pt,
-                         bias=st["bt"], out2=x1e, ldc2=r * cout, act2=1)
+                         bias=st["bt"], out2=x1e, ldc2=r * cout, act2=1, x3=self.x3)
             x1v = x1.view(Mout, cout)
             c3e = self._empty(Mout, cout // 2)
             oute = self._empty(Mout, cout)
@@ -255,8 +260,8 @@ class EncodecDecoder:
                               x2=x1v, cin2=cout)
             else:
                 ops.gemm(Mout, cout // 2, 3 * cout, ops.conv(x1e.view(Mout, cout), cout, n_out, n_out, L.PT_MAP_CAUSAL_REFLECT, taps=3),
-                         ops.plain(st["w3"]), c3e, pt, bias=st["b3"], act=1)
-                ops.gemm(Mout, cout, cout // 2 + cout, ops.concat(c3e, x1v), ops.plain(st["wf"]), oute, pt, bias=st["bf"], act=1)
+                         ops.plain(st["w3"]), c3e, pt, bias=st["b3"], act=1, x3=self.x3)
+                ops.gemm(Mout, cout, cout // 2 + cout, ops.concat(c3e, x1v), ops.plain(st["wf"]), oute, pt, bias=st["bf"], act=1, x3=self.x3)
             xe, n = oute, n_out
         wav = torch.empty(B * n, 1, dtype=torch.float32, device=self.device)
         self._rowconv(B, n, xe, 32, 7, L.PT_MAP_CAUSAL_REFLECT, self.wfin, self.bfin, 1, wav, y_f32=True)

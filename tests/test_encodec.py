@@ -365,3 +365,33 @@ def test_persistent_lstm_timeout_in_a_later_launch_of_the_call_is_sticky(dev, mo
     with pytest.raises(RuntimeError, match="timed out"):
         dec.decode(codes)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(20, 150), (70, 40), (5, 300)])
+def test_persistent_f32_lstm_decoder_vs_oracle(dev, B, T):
+    """f32 decode at sizes that take the PERSISTENT f32-class LSTM (bf16 x 3 products, hi / lo weight fragments in registers,
+    16-byte data-tagged granules): 2, 4 + 1 (two launches, ragged last cluster) and 1 cluster(s), against the CPU oracle at the
+    north_star bound for floating point (1e-3 of the waveform peak; the exact-f32 per-step kernels measure ~1e-6)."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    W = oe.random_weights(5)
+    codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(B + T))
+    got = EncodecDecoder(W, device=dev, dtype=torch.float32).decode(codes.to(dev)).cpu()
+    want = oe.decode(codes, W)
+    assert got.shape == want.shape == (B, 1, 320 * T) and torch.isfinite(got).all()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 1e-3, err
+
+
+@pytest.mark.gpu
+def test_persistent_f32_lstm_timeout_raises(dev, monkeypatch):
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    dec = EncodecDecoder(oe.random_weights(5), device=dev, dtype=torch.float32)
+    codes = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(3)).to(dev)
+    monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
+    monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "5")
+    with pytest.raises(RuntimeError, match="timed out"):
+        dec.decode(codes)
+    torch.cuda.synchronize()

@@ -184,6 +184,36 @@ def test_gemm_concat_operand(dev, dtype):
     assert relerr(dw, dyf.t() @ torch.cat([a1f, a2f], 1)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 136, 200), (1024, 512, 896), (4096, 256, 64)])
+def test_gemm_f32_x3_is_f32_class(dev, M, N, K):
+    """pt_gemm_desc.f32_x3: f32 operands multiplied as a bf16 x 3 split (hi hi + hi lo + lo hi on the bf16 MFMA).  Against an f64
+    product: error ~2^-16 per product -> well below 1e-4 of the result's scale, where a plain bf16 product sits at 4e-3; the
+    exact-f32 form (x3 = 0, the training parity mode) stays at 1e-6.  Same for a conv-gather operand with the ELU epilogue."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * K ** -0.5; bias = torch.randn(N, generator=g)
+    want = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    errs = {}
+    for x3 in (False, True):
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, ops.plain(ad), ops.plain(wd), out, L.PT_F32, bias=bd, x3=x3)
+        errs[x3] = float((out.cpu().double() - want).abs().max() / want.abs().max())
+    assert errs[False] < 2e-6 and errs[True] < 5e-5, errs
+    if K % 8 == 0 and M % 64 == 0:
+        Bb, n = 4, M // 4
+        cin = K
+        w3 = torch.randn(N, 3 * cin, generator=g) * (3 * cin) ** -0.5
+        x = a.view(Bb, n, cin)
+        xp = torch.cat([x[:, 2:3].flip(1), x[:, 1:2], x], 1)                       # causal reflect padding (k = 3): rows -2, -1 -> 2, 1
+        cols = torch.cat([xp[:, t:t + n] for t in range(3)], -1).reshape(M, 3 * cin)
+        ref = torch.nn.functional.elu(cols.double() @ w3.double().t() + bias.double())
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, 3 * cin, ops.conv(ad, cin, n, n, L.PT_MAP_CAUSAL_REFLECT, taps=3), ops.plain(w3.to(dev)), out, L.PT_F32, bias=bd,
+                 act=1, x3=True)
+        assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 5e-5
+
+
 def _attn_ref(q, k, v, scale, causal=False, kv_len=None):
     s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
     if kv_len is not None:
