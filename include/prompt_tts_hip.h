@@ -351,7 +351,9 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *     batch rows runs all T steps with the recurrent weights resident in LDS; clusters of 64 workgroups (one per CU) exchange
  *     the new hidden vectors every step through data-tagged 8-byte granules in h0_seq (its first 256 bytes hold the status
  *     word).  Every workgroup of a launch must be resident at once; every wait is bounded;
- *   - per step (PT_F32, other H, small devices, PT_LSTM_PERSIST=0): T + 1 dependent launches (layer 0 step s beside layer 1
+ *   - persistent, f32-class (PT_F32, same conditions, exact_f32 == 0): the same plan with bf16 x 3 products, the hi / lo weight
+ *     fragments of a workgroup in registers and 16-byte granules;
+ *   - per step (exact f32, other H, small devices, PT_LSTM_PERSIST=0): T + 1 dependent launches (layer 0 step s beside layer 1
  *     step s - 1).
  * `status`: device pointer to ONE 32-bit word owned by the caller, or NULL.  The call clears it on the stream; after the call
  * has completed on the stream, 0 = ok and non-zero = a hand-off of the persistent form timed out (out_elu is then INVALID:
@@ -362,6 +364,9 @@ typedef struct pt_lstm2_desc {
   const void* x; const void* xg0; const void* whh0; const void* wcat1; const float* bias1;
   void* h0_seq; void* h1_seq; float* c0; float* c1; void* out_elu;
   void* status;
+  int64_t exact_f32;     /* PT_F32: != 0 = always the per-step kernels on the exact f32 MFMA (the Encodec ENCODER, whose output
+                            feeds integer code decisions); 0 = the persistent f32-class form where it applies (bf16 x 3 products:
+                            ~1e-5 relative, for the decoder's 1e-3 waveform bound) */
 } pt_lstm2_desc;
 int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
 

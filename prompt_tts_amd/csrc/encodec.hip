@@ -307,6 +307,13 @@ struct LstmPersist {
   int fault_slice;          // >= 0: that workgroup publishes wrong tags (test hook: forces the timeout path); -1 in production
 };
 
+// PT_LSTM_REGW (default): the four waves split the reduction, so a wave needs only ITS k-steps of the workgroup's weights: 24 B
+// fragments = 96 registers per lane, resident for the whole kernel -- the MFMAs of a tick read no LDS (with the weights in LDS a
+// tick re-read 24 fragments per wave: 5.81 -> 5.13 ms per 64 x 1024 frames).  The 112 KiB LDS declaration stays: it is what keeps
+// the launch at one workgroup per CU (the hand-off protocol wants every workgroup resident, one per CU).
+#ifndef PT_LSTM_REGW
+#define PT_LSTM_REGW 1
+#endif
 __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist p) {
   __shared__ __attribute__((aligned(16))) char smem[LP_LDS];
   char* W0s = smem; char* W1s = smem + LP_W0_BYTES;
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
   const int rows = p.clusters * 16;
   if (tid == 0) *abort_flag = 0;
 
+#if !PT_LSTM_REGW
   // ---- resident weights: local gate column lc = gate * 8 + unit; 16-byte chunk ch of row lc lives at ch ^ (lc & 15) ----
   for (int q = tid; q < LP_COLS * 64; q += 256) {
     const int lc = q >> 6, ch = q & 63;
@@ -328,6 +336,22 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
     const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
     *reinterpret_cast<u32x4_t*>(W1s + lc * 2048 + ((ch ^ (lc & 15)) << 4)) = *reinterpret_cast<const u32x4_t*>(p.wcat1 + grow * 2 * LP_H + ch * 8);
   }
+#endif
+#if PT_LSTM_REGW
+  (void)W0s; (void)W1s;
+  Frag<bf16_t> rw0[4][2], rw1a[4][2], rw1b[4][2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int lc = 16 * tl + li;
+      const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
+      const int k0 = 32 * (4 * wave + k) + 8 * g;
+      frag_load_global(rw0[k][tl], p.whh0 + grow * LP_H + k0);
+      frag_load_global(rw1a[k][tl], p.wcat1 + grow * 2 * LP_H + k0);
+      frag_load_global(rw1b[k][tl], p.wcat1 + grow * 2 * LP_H + LP_H + k0);
+    }
+#endif
   // ---- gate-math role of this thread: (layer, batch row, unit) ----
   const int layer = tid >> 7, b = (tid >> 3) & 15, jj = tid & 7;
   const int bglob = p.b_base + 16 * c + b;
@@ -410,6 +434,12 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
           const int lc = 16 * tl + li;
+#if PT_LSTM_REGW
+          (void)lc; (void)ks;
+          if (l0) mma16(acc[tl], a0[k], rw0[k][tl]);
+          mma16(acc[2 + tl], a0[k], rw1a[k][tl]);
+          if (need1) mma16(acc[2 + tl], a1[k], rw1b[k][tl]);
+#else
           Frag<bf16_t> w0, w1a;
           w0.v = *reinterpret_cast<const bf16x8_t*>(W0s + lc * 1024 + (((4 * ks + g) ^ (lc & 15)) << 4));
           w1a.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((4 * ks + g) ^ (lc & 15)) << 4));
@@ -420,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
             w1b.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((64 + 4 * ks + g) ^ (lc & 15)) << 4));
             mma16(acc[2 + tl], a1[k], w1b);
           }
+#endif
         }
       }
     }
@@ -1156,7 +1187,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   // f32 (the reference's precision): the same persistent plan with bf16 x 3 products and register-resident hi / lo weights
   static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
   const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
-  if (persist && persist3 && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
+  if (persist && persist3 && !d->exact_f32 && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = 16 * max_clusters;
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {

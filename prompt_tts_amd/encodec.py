@@ -94,7 +94,7 @@ class LstmStatus:
                                "PT_LSTM_PERSIST=0 for the per-step kernels")
 
 
-def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None):
+def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None, exact_f32=False):
     """Two-layer LSTM + skip + ELU over (B*T, 512) token-major rows; returns (ELU(h1 + x), LstmStatus to check()).
     `status`: a reusable LstmStatus (pinned allocation is slow); it must have been check()ed since its last use."""
     M = B * T
@@ -106,6 +106,7 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None)
     ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = x.data_ptr(), xg0.data_ptr(), w_hh0.data_ptr(), wcat1.data_ptr(), bias1.data_ptr()
     ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
     ld.status = st.ptr()
+    ld.exact_f32 = int(exact_f32)      # the encoder: its embeddings feed integer code decisions -> exact f32 MFMA, per-step kernels
     check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
     st.fetch()
     return ze, st
@@ -395,7 +396,8 @@ class EncodecEncoder:
         M = B * T
         xg0 = self._empty(M, 2048)
         ops.gemm(M, 2048, 512, ops.plain(cur), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
-        ze, lstm_status = run_lstm2(B, T, cur, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status())
+        ze, lstm_status = run_lstm2(B, T, cur, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status(),
+                                    exact_f32=True)
         emb = torch.empty(M, 128, dtype=torch.float32, device=self.device)
         ops.gemm(M, 128, 7 * 512, ops.conv(ze, 512, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.wfin), emb, pt,
                  bias=self.bfin, out_kind=L.PT_OUT_F32 if self.dtype != torch.float32 else L.PT_OUT_T)

@@ -23,7 +23,7 @@ def timed(fn, n=30):
 
 
 row = f"tile={os.environ.get('PT_GEMM_TILE', 'auto'):>4}:"
-for M, N, K in [(32768, 512, 512), (16384, 512, 512), (32768, 1536, 512), (32768, 4096, 512), (32768, 512, 2048)]:
+for M, N, K in [(32768, 512, 512), (16384, 512, 512), (16384, 512, 1536), (16384, 1536, 512), (16384, 512, 2048), (32768, 1536, 512), (32768, 4096, 512), (32768, 512, 2048)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=dev); res = torch.randn(M, N, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
