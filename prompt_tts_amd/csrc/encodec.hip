@@ -736,19 +736,38 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
   const float bfin = p.bfin[0];
   const int n_out = 2 * p.n;
 
-  for (int tile = blockIdx.x; tile < p.B * p.tiles_per_item; tile += gridDim.x) {
+  // The input rows of the NEXT tile are fetched into registers while this tile's four compute phases run (the kernel is a chain of
+  // short dependent phases: fetched at the top of its own tile, the HBM latency of the 10 KiB input was exposed once per tile)
+  constexpr int TL_PF = (TL_RI * 8 + 255) / 256;
+  u32x4_t pf[TL_PF];
+  auto fetch = [&](int tile_) {
+    const int b_ = tile_ / p.tiles_per_item, n0_ = (tile_ - b_ * p.tiles_per_item) * TL_RIN;
+    const int ni0_ = n0_ >= TL_HALO ? n0_ - TL_HALO : 0;
+#pragma unroll
+    for (int k = 0; k < TL_PF; ++k) {
+      const int q = tid + 256 * k, i = q >> 3, ch = q & 7, nrow = ni0_ + i;
+      pf[k] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (q < TL_RI * 8 && nrow < p.n) pf[k] = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b_ * p.n + nrow) * p.ldx + 8 * ch);
+    }
+  };
+  const int n_tiles = p.B * p.tiles_per_item;
+  // the weight loads above are waited for HERE: left to hipcc, their counted waits (vmcnt(5), (3), (1) ...) sit at the first use
+  // inside the loop, and on every later tile the same waits drain the prefetch a few hundred cycles after it was issued
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) only
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * TL_RIN;
     const int ni0 = n0 >= TL_HALO ? n0 - TL_HALO : 0;           // first input row held in LDS
     const int t_base = 2 * ni0;                                  // output row of LDS row 0 of X1 / C3e / Oute
     __syncthreads();                                             // previous tile's LDS reads are done
-    // ---- A: input rows ni0 .. ni0 + 79 (zero beyond the item) ----
-    for (int q = tid; q < TL_RI * 8; q += 256) {
-      const int i = q >> 3, ch = q & 7, nrow = ni0 + i;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (nrow < p.n) v = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b * p.n + nrow) * p.ldx + 8 * ch);
-      *reinterpret_cast<u32x4_t*>(Xin + i * TL_XSTRIDE + 16 * ch) = v;
+    // ---- A: input rows ni0 .. ni0 + 79 (zero beyond the item), from the prefetch registers ----
+#pragma unroll
+    for (int k = 0; k < TL_PF; ++k) {
+      const int q = tid + 256 * k;
+      if (q < TL_RI * 8) *reinterpret_cast<u32x4_t*>(Xin + (q >> 3) * TL_XSTRIDE + 16 * (q & 7)) = pf[k];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- B: transposed conv: x1[i][rho*32 + co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*32+co][tap*64+ci] ----
     for (int rt = wave; rt < TL_RI / 16; rt += 4) {
       f32x4_t acc[4];
@@ -878,18 +897,33 @@ __global__ __launch_bounds__(256) void encodec_stage2_kernel(const Stage2Params 
     for (int r = 0; r < 4; ++r) bf4[nt][r] = p.bf[16 * nt + 4 * g + r];
   const int n_out = 4 * p.n;
 
-  for (int tile = blockIdx.x; tile < p.B * p.tiles_per_item; tile += gridDim.x) {
+  // next tile's input rows are fetched into registers under this tile's compute (see the tail kernel)
+  constexpr int S2_PF = S2_RI * 16 / 256;
+  u32x4_t pf[S2_PF];
+  auto fetch = [&](int tile_) {
+    const int b_ = tile_ / p.tiles_per_item, n0_ = (tile_ - b_ * p.tiles_per_item) * S2_RIN;
+    const int ni0_ = n0_ >= S2_HALO ? n0_ - S2_HALO : 0;
+#pragma unroll
+    for (int k = 0; k < S2_PF; ++k) {
+      const int q = tid + 256 * k, i = q >> 4, ch = q & 15, nrow = ni0_ + i;
+      pf[k] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (nrow < p.n) pf[k] = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b_ * p.n + nrow) * p.ldx + 8 * ch);
+    }
+  };
+  const int n_tiles = p.B * p.tiles_per_item;
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * S2_RIN;
     const int ni0 = n0 >= S2_HALO ? n0 - S2_HALO : 0;
     const int t_base = 4 * ni0;
     __syncthreads();
-    for (int q = tid; q < S2_RI * 16; q += 256) {
-      const int i = q >> 4, ch = q & 15, nrow = ni0 + i;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (nrow < p.n) v = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b * p.n + nrow) * p.ldx + 8 * ch);
-      *reinterpret_cast<u32x4_t*>(Xin + i * S2_XS + 16 * ch) = v;
+#pragma unroll
+    for (int k = 0; k < S2_PF; ++k) {
+      const int q = tid + 256 * k;
+      *reinterpret_cast<u32x4_t*>(Xin + (q >> 4) * S2_XS + 16 * (q & 15)) = pf[k];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- transposed conv: x1[4 i + rho][co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*64+co][tap*128+ci]; wave = rho ----
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -1016,14 +1050,29 @@ __global__ __launch_bounds__(256) void encodec_res1_kernel(const Res1Params p) {
     bf4[0][r] = p.bf[32 * wave + 4 * g + r]; bf4[1][r] = p.bf[32 * wave + 16 + 4 * g + r];
   }
 
-  for (int tile = blockIdx.x; tile < p.B * p.tiles_per_item; tile += gridDim.x) {
+  // next tile's input rows are fetched into registers under this tile's compute (see the tail kernel)
+  constexpr int R1_PF = R1_ROWS * 16 / 256;
+  u32x4_t pf[R1_PF];
+  auto fetch = [&](int tile_) {
+    const int b_ = tile_ / p.tiles_per_item, n0_ = (tile_ - b_ * p.tiles_per_item) * R1_OWN;
+    const int tb_ = n0_ >= 2 ? n0_ - 2 : 0;
+#pragma unroll
+    for (int k = 0; k < R1_PF; ++k) {
+      const int q = tid + 256 * k, i = q >> 4, ch = q & 15, row = tb_ + i;
+      pf[k] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (row < p.n) pf[k] = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b_ * p.n + row) * p.ldx + 8 * ch);
+    }
+  };
+  const int n_tiles = p.B * p.tiles_per_item;
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * R1_OWN;
     const int t_base = n0 >= 2 ? n0 - 2 : 0;
     __syncthreads();
-    for (int q = tid; q < R1_ROWS * 16; q += 256) {
-      const int i = q >> 4, ch = q & 15, row = t_base + i;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (row < p.n) v = *reinterpret_cast<const u32x4_t*>(p.x + ((int64_t)b * p.n + row) * p.ldx + 8 * ch);
+#pragma unroll
+    for (int k = 0; k < R1_PF; ++k) {
+      const int q = tid + 256 * k, i = q >> 4, ch = q & 15;
+      const u32x4_t v = pf[k];
       *reinterpret_cast<u32x4_t*>(X1r + i * R1_XS + 16 * ch) = v;
       u32x4_t e;
 #pragma unroll
@@ -1034,6 +1083,7 @@ __global__ __launch_bounds__(256) void encodec_res1_kernel(const Res1Params p) {
       *reinterpret_cast<u32x4_t*>(X1e + i * R1_XS + 16 * ch) = e;
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- c3e[j][16 w ..] = ELU(b3 + conv k3 over ELU(x1), causal with reflect at the item start) ----
 #pragma unroll
     for (int rt = 0; rt < R1_ROWS / 16; ++rt) {
