@@ -347,12 +347,14 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *   layer 1 uses wcat1 [4H][2H] = [W_ih1 | W_hh1] and bias1 [4H] = b_ih1 + b_hh1
  *   out_elu[(b,t)][:] = ELU(h1_t + x[(b,t)][:])
  * h0_seq, h1_seq [B*T][H] and c0, c1 [B][H] (f32) are caller-provided scratch.  Two forms, chosen by the library:
- *   - persistent (PT_BF16, H = 512, B*T*H*2 >= 256 KiB + 256, a device with >= 64 CUs): ONE launch per 16 * min(4, CUs / 64)
- *     batch rows runs all T steps with the recurrent weights resident in LDS; clusters of 64 workgroups (one per CU) exchange
- *     the new hidden vectors every step through data-tagged 8-byte granules in h0_seq (its first 256 bytes hold the status
- *     word).  Every workgroup of a launch must be resident at once; every wait is bounded;
- *   - persistent, f32-class (PT_F32, same conditions, exact_f32 == 0): the same plan with bf16 x 3 products, the hi / lo weight
- *     fragments of a workgroup in registers and 16-byte granules;
+ *   - persistent (PT_BF16, H = 512, B*T*H*2 >= 256 KiB + 512, a device with >= 32 CUs): ONE launch per 8 * min(8, CUs / 32)
+ *     batch rows runs all T steps with the recurrent weights resident in registers; clusters of 8 rows x 32 workgroups (one per
+ *     CU) exchange the new hidden vectors every step through data-tagged 8-byte granules in h0_seq (its first 512 bytes hold the
+ *     status word and the launch's XCD census).  Where the census finds every cluster on one XCD (a 256-CU device: read from the
+ *     hardware per launch, never assumed) the exchange stays in that XCD's L2; otherwise it goes through memory (PT_LSTM_FORCE_
+ *     REMOTE=1 forces that form).  Every workgroup of a launch must be resident at once; every wait is bounded;
+ *   - persistent, f32-class (PT_F32, >= 64 CUs, exact_f32 == 0): clusters of 16 rows x 64 workgroups, bf16 x 3 products, the hi /
+ *     lo weight fragments of a workgroup in registers and 16-byte granules, exchange through memory;
  *   - per step (exact f32, other H, small devices, PT_LSTM_PERSIST=0): T + 1 dependent launches (layer 0 step s beside layer 1
  *     step s - 1).
  * `status`: device pointer to ONE 32-bit word owned by the caller, or NULL.  The call clears it on the stream; after the call

@@ -278,25 +278,21 @@ __global__ __launch_bounds__(256) void lstm2_step_kernel(const LstmParams p, int
 }
 
 
-// ---- persistent 2-layer LSTM (bf16, H = 512): ONE launch for all T steps ---------------------------------------------------
+// ---- persistent 2-layer LSTM (H = 512): ONE launch for all T steps ---------------------------------------------------------
 // The recurrence is T dependent steps of two tiny GEMMs ([B x 512] x [512 x 2048] and [B x 1024] x [1024 x 2048]): as T + 1
 // launches each step re-reads 6 MiB of weights from L2 and pays a launch boundary (~14 us per step at B = 64).  Here the
-// weights are RESIDENT: the batch is cut into clusters of 16 rows (one MFMA tile) and each cluster runs on 64 workgroups, one per
-// CU, workgroup u owning hidden units 8u .. 8u+7 of BOTH layers (4 gates x 8 units = 32 gate columns: 32 KiB + 64 KiB of
-// weights in LDS for the whole kernel, cell states in registers).  Per tick s the workgroup computes layer 0 at t = s and layer 1
-// at t = s - 1 (both need only h0_{s-1} and h1_{s-2}) and hands its 2 x 16 x 8 new hidden values to its 63 peers.
+// weights are RESIDENT in registers: the batch is cut into clusters of rows, a cluster runs on a fixed set of workgroups (one per
+// CU), each owning a slice of the hidden units of BOTH layers; per tick s a workgroup computes layer 0 at t = s and layer 1 at
+// t = s - 1 (both need only h0_{s-1} and h1_{s-2}) and hands its new hidden values to its peers.
 // Hand-off = data-tagged granules (the microarchitecture guide's R2 form: "the data IS the flag"): a granule is one naturally
-// aligned 8-byte {tag = tick + 1, two bf16 hidden values} written by ONE agent-scope (sc1, write-through) store; a consumer
-// reads the granules it needs with sc1 loads (16 bytes = two whole granules) and simply re-reads until every tag shows the
-// tick it is waiting for -- no counter, no flag, no fence, one memory round trip less than payload + drain + flag + poll
-// (measured: 9.3 us per tick with the counter form).  The four granules a lane reads per k-step ARE its MFMA A fragment.
-// Two parity buffers suffice: a workgroup can overwrite buf[s & 1] (tick s + 2) only after it has consumed every peer's tick
-// s + 1 data, which each peer publishes after its own reads of buf[s & 1].  All 64 x clusters <= 256 workgroups must be co-
-// resident: 1 per CU (112 KiB LDS), at most 4 clusters per launch; every spin is bounded and a timeout raises the error word
-// (first word of the workspace) instead of hanging.
-constexpr int LP_UNITS = 8, LP_SLICES = 64, LP_H = 512, LP_COLS = 32;
-constexpr int LP_W0_BYTES = LP_COLS * LP_H * 2, LP_W1_BYTES = LP_COLS * 2 * LP_H * 2, LP_RED_BYTES = 4 * 4 * 4 * 64 * 4;
-constexpr int LP_LDS = LP_W0_BYTES + LP_W1_BYTES + LP_RED_BYTES + 64;
+// aligned 8-byte {two bf16 hidden values, tag = tick + 1} written by ONE store; a consumer reads the granules it needs with
+// L1-bypassing loads (16 bytes = two whole granules) and re-reads until every tag shows the tick it is waiting for -- no
+// counter, no flag, no fence (measured: 9.3 us per tick with the counter form).  The granules a lane reads per k-step ARE its MFMA
+// A fragment.  Two parity buffers suffice: a workgroup can overwrite buf[s & 1] (tick s + 2) only after it has consumed every
+// peer's tick s + 1 data, which each peer publishes after its own reads of buf[s & 1].  Every workgroup of a launch must be
+// resident at once (one per CU); every spin is bounded and a timeout raises the status word instead of hanging.
+// bf16: lstm2_persist8_kernel (8-row clusters x 32 workgroups = one XCD); f32-class: lstm2_persist3_kernel (16 rows x 64).
+constexpr int LP_UNITS = 8, LP_SLICES = 64, LP_H = 512;
 struct LstmPersist {
   int B, T, b_base, clusters;
   const bf16_t* x; const bf16_t* xg0; const bf16_t* whh0; const bf16_t* wcat1; const float* bias1;
@@ -305,115 +301,207 @@ struct LstmPersist {
   unsigned* err;            // status word (pt_lstm2_desc.status or the first word of the workspace); zeroed once per CALL
   int spin_limit;           // poll rounds before a hand-off counts as lost (2^20 ~ a second; tests shrink it)
   int fault_slice;          // >= 0: that workgroup publishes wrong tags (test hook: forces the timeout path); -1 in production
+  unsigned* census;         // lstm2_persist8_kernel: [0..7] workgroups seen per XCD, [8] their total; zeroed by the launch function
+  int force_remote;         // test hook: 1 = take the cross-XCD form even where every cluster could sit on one XCD
 };
 
-// PT_LSTM_REGW (default): the four waves split the reduction, so a wave needs only ITS k-steps of the workgroup's weights: 24 B
-// fragments = 96 registers per lane, resident for the whole kernel -- the MFMAs of a tick read no LDS (with the weights in LDS a
-// tick re-read 24 fragments per wave: 5.81 -> 5.13 ms per 64 x 1024 frames).  The 112 KiB LDS declaration stays: it is what keeps
-// the launch at one workgroup per CU (the hand-off protocol wants every workgroup resident, one per CU).
-#ifndef PT_LSTM_REGW
-#define PT_LSTM_REGW 1
-#endif
-__global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist p) {
-  __shared__ __attribute__((aligned(16))) char smem[LP_LDS];
-  char* W0s = smem; char* W1s = smem + LP_W0_BYTES;
-  float* red = reinterpret_cast<float*>(smem + LP_W0_BYTES + LP_W1_BYTES);
-  int* abort_flag = reinterpret_cast<int*>(smem + LP_W0_BYTES + LP_W1_BYTES + LP_RED_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
-  const int c = blockIdx.x / LP_SLICES, u = blockIdx.x % LP_SLICES;
-  const int rows = p.clusters * 16;
-  if (tid == 0) *abort_flag = 0;
+// gate math: one v_exp_f32 + one v_rcp_f32 per gate (1 ulp each; the result is rounded to bf16 for the hand-off)
+__device__ __forceinline__ float lp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+// tanh x = 1 - 2 / (1 + e^{2x}); e^{2x} = inf gives 1, 0 gives -1
+__device__ __forceinline__ float lp_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x)); }
+__device__ __forceinline__ void lp_load_w(Frag<bf16_t>& f, const bf16_t* p) {       // slots 0..3 = p[0..3], slots 4..7 = p[16..19]
+  typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+  const u2 lo = *reinterpret_cast<const u2*>(p), hi = *reinterpret_cast<const u2*>(p + 16);
+  const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+  f.v = __builtin_bit_cast(bf16x8_t, v);
+}
 
-#if !PT_LSTM_REGW
-  // ---- resident weights: local gate column lc = gate * 8 + unit; 16-byte chunk ch of row lc lives at ch ^ (lc & 15) ----
-  for (int q = tid; q < LP_COLS * 64; q += 256) {
-    const int lc = q >> 6, ch = q & 63;
-    const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
-    *reinterpret_cast<u32x4_t*>(W0s + lc * 1024 + ((ch ^ (lc & 15)) << 4)) = *reinterpret_cast<const u32x4_t*>(p.whh0 + grow * LP_H + ch * 8);
-  }
-  for (int q = tid; q < LP_COLS * 128; q += 256) {
-    const int lc = q >> 7, ch = q & 127;
-    const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
-    *reinterpret_cast<u32x4_t*>(W1s + lc * 2048 + ((ch ^ (lc & 15)) << 4)) = *reinterpret_cast<const u32x4_t*>(p.wcat1 + grow * 2 * LP_H + ch * 8);
-  }
+// Diagnostic build (-DLSTM_TRACE=1, `make exp`): thread 0 of workgroups 0 / 10 / 20 / 30 of cluster 0 stamps s_memtime at the phase
+// boundaries of ticks 200 .. 263 (tools/lstm_trace.py prints the differences)
+#ifndef LSTM_TRACE
+#define LSTM_TRACE 0
 #endif
-#if PT_LSTM_REGW
-  (void)W0s; (void)W1s;
-  Frag<bf16_t> rw0[4][2], rw1a[4][2], rw1b[4][2];
+#if LSTM_TRACE
+// stamps go to LDS (a global store per stamp put its own acknowledgement into every later s_waitcnt vmcnt) and are copied out at
+// the end of the kernel
+__device__ unsigned long long lstm_trace_buf[4 * 64 * 8];
+#define LT_DECL __shared__ unsigned long long tr_lds[64 * 8];
+#define LT_STAMP(i) do { if (tr_slot >= 0 && s >= 200 && s < 264 && tid == 0) tr_lds[(s - 200) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LT_VALUE(i, v) do { if (tr_slot >= 0 && s >= 200 && s < 264 && tid == 0) tr_lds[(s - 200) * 8 + (i)] = (unsigned long long)(v); } while (0)
+#define LT_FLUSH do { __syncthreads(); if (tr_slot >= 0 && tid < 64) for (int q = tid; q < 512; q += 64) lstm_trace_buf[tr_slot * 512 + q] = tr_lds[q]; } while (0)
+#else
+#define LT_DECL
+#define LT_STAMP(i) do { } while (0)
+#define LT_VALUE(i, v) do { } while (0)
+#define LT_FLUSH do { } while (0)
+#endif
+// ---- persistent 2-layer LSTM, bf16: 8-row clusters x 32 workgroups ----------------------------------------------------------
+// Rounds 2 - 3 ran clusters of 16 rows x 64 workgroups (8 units each, 5.0 us per tick).  In-kernel stamps (tools/lstm_trace.py)
+// showed what bounded that tick, and it was not arithmetic: every poll succeeded on its FIRST round and still took 4 700 - 5 700
+// of the tick's 12 000 cycles -- the 64 KiB of granules a workgroup pulls in per tick arrive at ~10 bytes per cycle per CU -- and
+// three things around it that hipcc had arranged: the input-gate loads converted (hence waited for) inside the divergent branch
+// that issued them, at the top of the tick (1 600 cycles); IEEE divisions and the library tanhf in the gate math (1 300); whole-
+// accumulator-array copies around every conditional MFMA (1 300 v_mov per tick).  This form:
+//   * clusters of EIGHT rows x 32 workgroups, workgroup u owning hidden units 16 u .. 16 u + 15 of both layers (64 gate columns
+//     per layer = four MFMA column tiles, tile = gate; 192 KiB of weights as 48 register-resident B fragments per wave): a
+//     workgroup pulls 32 KiB per tick (rows 8 .. 15 of the MFMA row tile are empty: their lanes load nothing) for twice the
+//     MFMAs (48 per wave and tick, back to back);
+//   * cluster = XCD where the hardware allows it (see the census below): the hand-off then never leaves one L2;
+//   * inputs fetched one tick ahead as raw bits, v_exp / v_rcp gate math, unconditional MFMAs (zero operands instead of branches).
+// 3.4 us per tick on 64 x 1024 frames (stamps: ~3 300 cycles of poll round + ~3 300 of MFMA / reduce / gates / publish).
+constexpr int L8_UNITS = 16, L8_SLICES = 32, L8_ROWS = 8;
+constexpr int L8_RED_FLOATS = 4 * 8 * 4 * 32;                 // [wave][layer * 4 + gate][r][lane & 31]
+
+template <int AUX>
+__device__ __forceinline__ void l8_load16(u32x4_t (&v)[16], __amdgpu_buffer_rsrc_t grs, int voff0, int voff1, bool need1) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, AUX);
+    v[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k + 64, 0, AUX);
+  }
+  if (need1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[8 + 2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, AUX);
+      v[8 + 2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k + 64, 0, AUX);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersist p) {
+  // one workgroup per CU by register count: ~500 registers per lane leave no room for a second wave on a SIMD
+  __shared__ float red[L8_RED_FLOATS];
+  __shared__ int abort_word;
+  int* abort_flag = &abort_word;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int rows = p.clusters * L8_ROWS;
+  // ---- census: which XCD am I on?  A cluster is 32 workgroups, an XCD is 32 CUs, a launch is 8 x 32 workgroups at one per CU:
+  // when every XCD turns out to hold exactly 32 of them (read from HW_REG_XCC_ID, not assumed from blockIdx), cluster = XCD and the
+  // hand-off never leaves that XCD's L2: PLAIN stores keep the granule lines there and the peers' sc1 loads (L1 bypassed, L2
+  // served) hit them -- sc1 stores drop the line to memory, and a store -> visible -> load hand-off through the fabric was
+  // ~5 500 of a tick's 10 000 cycles (in-kernel stamps).  Any other census (fewer CUs, a partitioned device, a launch that is not
+  // 256 workgroups) takes the placement-independent form: cluster = blockIdx / 32, sc1 stores.
+  __shared__ int cfg[3];
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 15u;            // HW_REG_XCC_ID (id 20), bits 3:0
+    const unsigned ticket = __hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p.census + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spin = 0;
+    bool lost = false;
+    while (__hip_atomic_load(p.census + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x) {
+      if (++spin > p.spin_limit) { lost = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    bool local = !lost && !p.force_remote && gridDim.x == 8 * L8_SLICES && xcc < 8u;
+    for (int x = 0; x < 8 && local; ++x)
+      local = __hip_atomic_load(p.census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)L8_SLICES;
+    if (lost) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cfg[0] = lost ? -1 : (local ? (int)xcc : (int)(blockIdx.x / L8_SLICES));
+    cfg[1] = local ? (int)ticket : (int)(blockIdx.x % L8_SLICES);
+    cfg[2] = local;
+    *abort_flag = 0;
+  }
+  __syncthreads();
+  const int c = __builtin_amdgcn_readfirstlane(cfg[0]), u = __builtin_amdgcn_readfirstlane(cfg[1]);
+  const bool local = __builtin_amdgcn_readfirstlane(cfg[2]) != 0;
+  if (c < 0 || c >= p.clusters) return;                     // census lost (status word set) / a cluster this launch has no rows for
+  LT_DECL
+#if LSTM_TRACE
+  const int tr_slot = (c == 0 && u % 10 == 0 && u < 40) ? u / 10 : -1;
+#endif
+
+  // B fragments of this wave's k-steps: column tile tl = gate, column li = unit 16 u + li; slot j of lane (li, g) in k-step ks
+  // stands for hidden unit 32 ks + 16 (j >> 2) + 4 g + (j & 3) (the order the granule loads deliver the A operand)
+  Frag<bf16_t> rw0[4][4], rw1a[4][4], rw1b[4][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int tl = 0; tl < 2; ++tl) {
-      const int lc = 16 * tl + li;
-      const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
-      const int k0 = 32 * (4 * wave + k) + 8 * g;
-      frag_load_global(rw0[k][tl], p.whh0 + grow * LP_H + k0);
-      frag_load_global(rw1a[k][tl], p.wcat1 + grow * 2 * LP_H + k0);
-      frag_load_global(rw1b[k][tl], p.wcat1 + grow * 2 * LP_H + LP_H + k0);
+    for (int tl = 0; tl < 4; ++tl) {
+      const int64_t grow = (int64_t)tl * LP_H + L8_UNITS * u + li;
+      const int k0 = 32 * (4 * wave + k) + 4 * g;
+      lp_load_w(rw0[k][tl], p.whh0 + grow * LP_H + k0);
+      lp_load_w(rw1a[k][tl], p.wcat1 + grow * 2 * LP_H + k0);
+      lp_load_w(rw1b[k][tl], p.wcat1 + grow * 2 * LP_H + LP_H + k0);
     }
-#endif
   // ---- gate-math role of this thread: (layer, batch row, unit) ----
-  const int layer = tid >> 7, b = (tid >> 3) & 15, jj = tid & 7;
-  const int bglob = p.b_base + 16 * c + b;
+  const int layer = tid >> 7, b = (tid >> 4) & 7, jj = tid & 15;
+  const int bglob = p.b_base + L8_ROWS * c + b;
   const bool bvalid = bglob < p.B;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
   if (layer == 1) {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + LP_UNITS * u + jj];
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + L8_UNITS * u + jj];
   }
   float cstate = 0.f;
   const int gbytes = 2 * 2 * rows * 256 * 8;
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, gbytes, 0x00020000);
   __syncthreads();
 
+  // Inputs that do not depend on the exchange -- layer 0's input gates of a tick, layer 1's skip x -- are fetched ONE TICK AHEAD, as
+  // raw bits: fetched at the top of their own tick, hipcc converted them inside the divergent branch that loads them, and the
+  // s_waitcnt in front of that conversion put a whole HBM latency in front of the poll
+  uint16_t xin[4] = {0, 0, 0, 0};
+  auto fetch_inputs = [&](int s_) {
+    if (layer == 0) {
+      if (s_ < p.T && bvalid) {
+        const bf16_t* xp = p.xg0 + ((int64_t)bglob * p.T + s_) * (4 * LP_H) + L8_UNITS * u + jj;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) xin[gi] = xp[gi * LP_H].bits;
+      }
+    } else if (s_ >= 1 && s_ <= p.T && bvalid) {
+      xin[0] = p.x[((int64_t)bglob * p.T + (s_ - 1)) * LP_H + L8_UNITS * u + jj].bits;
+    }
+  };
+  fetch_inputs(0);
+  float xg_next[4];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) xg_next[gi] = bf16_bits_to_f32(xin[gi]);
+  const bool loader = li < L8_ROWS;                        // lanes of the empty rows 8 .. 15 load nothing and multiply zeros
+
   for (int s = 0; s <= p.T; ++s) {
     const bool l0 = s < p.T, l1 = s >= 1;
-    // inputs that do not depend on the exchange are fetched ahead of it: layer 0's input gates of this tick, layer 1's skip x
-    float xg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (layer == 0 && l0 && bvalid) {
-      const bf16_t* xp = p.xg0 + ((int64_t)bglob * p.T + s) * (4 * LP_H) + LP_UNITS * u + jj;
+    float xg[4];                                            // layer 1: xg[0] is the skip input
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi) xg[gi] = to_f32<bf16_t>(xp[gi * LP_H]);
-    }
-    float xskip = 0.f;
-    const int64_t oi1 = ((int64_t)bglob * p.T + (s - 1)) * LP_H + LP_UNITS * u + jj;
-    if (layer == 1 && l1 && bvalid) xskip = to_f32<bf16_t>(p.x[oi1]);
+    for (int gi = 0; gi < 4; ++gi) xg[gi] = xg_next[gi];
+    const int64_t oi1 = ((int64_t)bglob * p.T + (s - 1)) * LP_H + L8_UNITS * u + jj;
+    if (s == 0) fetch_inputs(1);                            // later ticks: right behind the poll
 
-    f32x4_t acc[4];                                         // [layer * 2 + tile]: D[row = batch][col = local gate column]
+    LT_STAMP(0);
+    f32x4_t acc[8];                                         // [layer * 4 + gate]: D[row = batch][col = unit]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (s >= 1) {
-      // h0_{s-1} (and h1_{s-2}): this lane's row li of the cluster, k-steps 4 wave .. 4 wave + 3; granules of one k-step are 32
-      // contiguous bytes; every tag must read s (the tick whose values they carry, plus 1)
       const int par = (s - 1) & 1;
       const unsigned want = (unsigned)s;
-      const int voff0 = (((par * 2 + 0) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 8;
-      const int voff1 = (((par * 2 + 1) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 8;
+      const int row = L8_ROWS * c + (li & 7);
+      const int voff0 = (((par * 2 + 0) * rows + row) * 256 + 64 * wave + 2 * g) * 8;
+      const int voff1 = (((par * 2 + 1) * rows + row) * 256 + 64 * wave + 2 * g) * 8;
       Frag<bf16_t> a0[4], a1[4];
       const bool need1 = s >= 2;
       int spin = 0;
+#if LSTM_TRACE
+      unsigned long long t_first = 0;
+      const unsigned long long t_poll0 = __builtin_amdgcn_s_memtime();
+#endif
       for (;;) {
         u32x4_t v[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, 16);
-          v[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k + 16, 0, 16);
-        }
-        if (need1) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[8 + 2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, 16);
-            v[8 + 2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k + 16, 0, 16);
-          }
+        for (int i = 0; i < 16; ++i) v[i] = (u32x4_t){0u, want, 0u, want};
+        if (loader) {
+          // cross-XCD form: sc1 loads.  XCD-local form: nt loads -- both bypass the L1, but an sc1 load of a line that a peer has
+          // just dirtied in this L2 took ~3 300 cycles per round (the same 16 loads repeated right away: 1 400), an nt load
+          // is a plain L2 hit
+          if (local) l8_load16<2>(v, grs, voff0, voff1, need1);
+          else l8_load16<16>(v, grs, voff0, voff1, need1);
         }
         bool ok = true;                                     // a granule is {low word: two bf16, high word: tag}
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ok &= (v[i][1] == want) & (v[i][3] == want);
-        if (need1) {
-#pragma unroll
-          for (int i = 8; i < 16; ++i) ok &= (v[i][1] == want) & (v[i][3] == want);
-        }
-        if (__all(ok)) {
+        for (int i = 0; i < 16; ++i) ok &= (v[i][1] == want) & (v[i][3] == want);
+        const bool all_ok = __all(ok);
+#if LSTM_TRACE
+        if (spin == 0) t_first = __builtin_amdgcn_s_memtime() - t_poll0;
+#endif
+        if (all_ok) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const u32x4_t w = {v[2 * k][0], v[2 * k][2], v[2 * k + 1][0], v[2 * k + 1][2]};
@@ -421,6 +509,9 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
             const u32x4_t w1 = {v[8 + 2 * k][0], v[8 + 2 * k][2], v[8 + 2 * k + 1][0], v[8 + 2 * k + 1][2]};
             a1[k].v = __builtin_bit_cast(bf16x8_t, w1);
           }
+          LT_STAMP(1);
+          LT_VALUE(7, (unsigned long long)spin | (t_first << 16));
+          fetch_inputs(s + 1);
           break;
         }
         if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -430,74 +521,83 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist_kernel(const LstmPersist
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ks = 4 * wave + k;
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-          const int lc = 16 * tl + li;
-#if PT_LSTM_REGW
-          (void)lc; (void)ks;
-          if (l0) mma16(acc[tl], a0[k], rw0[k][tl]);
-          mma16(acc[2 + tl], a0[k], rw1a[k][tl]);
-          if (need1) mma16(acc[2 + tl], a1[k], rw1b[k][tl]);
-#else
-          Frag<bf16_t> w0, w1a;
-          w0.v = *reinterpret_cast<const bf16x8_t*>(W0s + lc * 1024 + (((4 * ks + g) ^ (lc & 15)) << 4));
-          w1a.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((4 * ks + g) ^ (lc & 15)) << 4));
-          if (l0) mma16(acc[tl], a0[k], w0);
-          mma16(acc[2 + tl], a0[k], w1a);
-          if (need1) {
-            Frag<bf16_t> w1b;
-            w1b.v = *reinterpret_cast<const bf16x8_t*>(W1s + lc * 2048 + (((64 + 4 * ks + g) ^ (lc & 15)) << 4));
-            mma16(acc[2 + tl], a1[k], w1b);
-          }
-#endif
+        for (int tl = 0; tl < 4; ++tl) {
+          // no conditions here: the last tick's layer-0 result is simply not used, and h1 is all zeros while there is none
+          // (tick 1) -- around conditional MFMAs hipcc copied the whole accumulator array (1 300 v_mov per tick)
+          mma16(acc[tl], a0[k], rw0[k][tl]);
+          mma16(acc[4 + tl], a0[k], rw1a[k][tl]);
+          mma16(acc[4 + tl], a1[k], rw1b[k][tl]);
         }
       }
     }
+    LT_STAMP(2);
     __syncthreads();                                        // the gate math of the previous tick has finished reading `red`
+    LT_STAMP(3);
     if (*abort_flag) return;
-    // partial sums of the four waves (each took a quarter of the reduction) -> LDS
+    // partial sums of the four waves (each took a quarter of the reduction) -> LDS; accumulator rows 4 g + r, g < 2, are the batch
+    if (g < 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * 4 + i) * 4 + r) * 64 + lane] = acc[i][r];
+        for (int r = 0; r < 4; ++r) red[((wave * 8 + i) * 4 + r) * 32 + (lane & 31)] = acc[i][r];
+    }
     __syncthreads();
+    LT_STAMP(4);
     const bool active = layer == 0 ? l0 : l1;
     float hn = 0.f;
     if (active) {
       float pre[4];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        const int tile = layer * 2 + (gi >> 1), src_lane = ((gi & 1) * 8 + jj) + 16 * (b >> 2), r = b & 3;
+        const int tile = layer * 4 + gi, src_lane = jj + 16 * (b >> 2), r = b & 3;
         float v = layer == 0 ? xg[gi] : bias[gi];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[((w * 4 + tile) * 4 + r) * 64 + src_lane];
+        for (int w = 0; w < 4; ++w) v += red[((w * 8 + tile) * 4 + r) * 32 + src_lane];
         pre[gi] = v;
       }
-      const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanhf(pre[2]), og = sigmoid_f(pre[3]);
+      const float ig = lp_sigmoid(pre[0]), fg = lp_sigmoid(pre[1]), gg = lp_tanh(pre[2]), og = lp_sigmoid(pre[3]);
       cstate = fg * cstate + ig * gg;
-      hn = og * tanhf(cstate);
+      hn = og * lp_tanh(cstate);
     }
+    // the next tick's inputs leave their load registers HERE, in front of the publish: the wait then covers loads issued a few
+    // thousand cycles ago and not the stores behind them (one in-order counter)
+    // (an explicit wait: left to hipcc, the conversions sink into the loop latch, behind the stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) xg_next[gi] = bf16_bits_to_f32(xin[gi]);
+    LT_STAMP(5);
     if (s < p.T) {
       // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row pair up into one granule {two bf16, tag s + 1}, stored by the even lane
       const unsigned mine = (unsigned)f32_to_bf16_bits(hn);
       const unsigned other = (unsigned)__shfl_down((int)mine, 1, 64);
       if ((jj & 1) == 0) {
-        const unsigned tag = (unsigned)(s + 1) + ((int)blockIdx.x == p.fault_slice ? 0x40000000u : 0u);
+        const unsigned tag = (unsigned)(s + 1) + (c * L8_SLICES + u == p.fault_slice ? 0x40000000u : 0u);   // (cluster, slice) role, not blockIdx
         const unsigned long long gran = ((unsigned long long)tag << 32) | (unsigned long long)(mine | (other << 16));
-        unsigned long long* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + 16 * c + b)) * 256 + (LP_UNITS * u + jj) / 2;
-        __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
+        if (local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");     // stays in this XCD's L2
+        else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    LT_STAMP(6);
     if (active && layer == 1 && bvalid) {
-      const float v = hn + xskip;
+      const float v = hn + xg[0];
       p.out_elu[oi1] = from_f32<bf16_t>(v < 0.f ? (__expf(v) - 1.f) : v);
     }
   }
+  LT_FLUSH;
 }
 
+#if LSTM_TRACE
+}  // namespace
+extern "C" int pt_debug_lstm_trace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lstm_trace_buf), sizeof(unsigned long long) * (n < 2048 ? n : 2048)) == hipSuccess ? 0 : -3;
+}
+namespace {
+#endif
+
 // ---- persistent 2-layer LSTM, f32-class arithmetic (PT_F32: the reference's precision, decode_codec.py:12-16) ------------------
-// Same plan as lstm2_persist_kernel -- clusters of 16 batch rows x 64 workgroups, workgroup u owns hidden units 8u .. 8u+7 of both
+// The plan of the header above with clusters of 16 batch rows x 64 workgroups, workgroup u owns hidden units 8u .. 8u+7 of both
 // layers, one data-tagged hand-off per tick -- with every product carried as a bf16 x 3 split:
 //     W = Whi + Wlo,  h = hhi + hlo  (bf16 each)      W h  ~  Whi hhi + Whi hlo + Wlo hhi      (error ~2^-16 per product)
 // which costs 3 bf16 MFMAs where the exact-f32 MFMA costs 16.  The 32 x 1536 weights of a workgroup do not fit LDS as hi + lo
@@ -515,11 +615,13 @@ struct LstmPersist3 {
   unsigned* err; int spin_limit; int fault_slice;
 };
 
+// slot j <- w[8 (j >> 1) + (j & 1)]: the k-order in which the granule loads of lstm2_persist3_kernel deliver the A operand
 __device__ __forceinline__ void split_bf16x8(const float* w, Frag<bf16_t>& hi, Frag<bf16_t>& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)w[j];
-    hi.v[j] = h; lo.v[j] = (__bf16)(w[j] - (float)h);
+    const float x = w[8 * (j >> 1) + (j & 1)];
+    const __bf16 h = (__bf16)x;
+    hi.v[j] = h; lo.v[j] = (__bf16)(x - (float)h);
   }
 }
 
@@ -531,7 +633,8 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
   const int rows = p.clusters * 16;
   if (tid == 0) abort_flag = 0;
 
-  // ---- resident weights as register B fragments: column lc = 16 tl + li (gate 2 tl + (li >> 3), unit li & 7), k = 32 ks + 8 g + j;
+  // ---- resident weights as register B fragments: column lc = 16 tl + li (gate 2 tl + (li >> 3), unit li & 7); slot j of lane
+  //      (li, g) in k-step ks = hidden unit 32 ks + 8 (j >> 1) + 2 g + (j & 1), the order the granule loads deliver the A operand;
   //      this wave's k-steps: layer 0: 4 wave + k; layer 1: 4 wave + k (h0 part) and 16 + 4 wave + k (h1 part) ----
   Frag<bf16_t> w0h[4][2], w0l[4][2], w1ah[4][2], w1al[4][2], w1bh[4][2], w1bl[4][2];
 #pragma unroll
@@ -540,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
     for (int tl = 0; tl < 2; ++tl) {
       const int lc = 16 * tl + li;
       const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
-      const int k0 = 32 * (4 * wave + k) + 8 * g;
+      const int k0 = 32 * (4 * wave + k) + 2 * g;
       split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
       split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
       split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], w1bl[k][tl]);
@@ -575,26 +678,29 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (s >= 1) {
-      // h0_{s-1} (and h1_{s-2}): row li of the cluster, this wave's k-steps; the 8 units of a fragment are 4 granules = 64
-      // contiguous bytes; every tag word must read s
+      // h0_{s-1} (and h1_{s-2}): row li of the cluster, this wave's k-steps; the 16 granules of a k-step are 256 contiguous bytes
+      // and load i of a lane takes granule 4 i + g: the four lanes of a row cover ONE whole 64-byte sector per load instruction
+      // (64 contiguous bytes per lane made each of the four loads touch all four sectors); every tag word must read s
       const int par = (s - 1) & 1;
       const unsigned want = (unsigned)s;
-      const int voff0 = (((par * 2 + 0) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 16;
-      const int voff1 = (((par * 2 + 1) * rows + 16 * c + li) * 256 + 64 * wave + 4 * g) * 16;
+      const int voff0 = (((par * 2 + 0) * rows + 16 * c + li) * 256 + 64 * wave + g) * 16;
+      const int voff1 = (((par * 2 + 1) * rows + 16 * c + li) * 256 + 64 * wave + g) * 16;
       const bool need1 = s >= 2;
       u32x4_t v0[16], v1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v1[i] = (u32x4_t){0u, 0u, 0u, 0u};
       int spin = 0;
       bool aborted = false;
       for (;;) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v0[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 256 * k + 16 * i, 0, 16);
+          for (int i = 0; i < 4; ++i) v0[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 256 * k + 64 * i, 0, 16);
         if (need1) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v1[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 256 * k + 16 * i, 0, 16);
+            for (int i = 0; i < 4; ++i) v1[4 * k + i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 256 * k + 64 * i, 0, 16);
         }
         bool ok = true;
 #pragma unroll
@@ -622,9 +728,10 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
           a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
 #pragma unroll
           for (int tl = 0; tl < 2; ++tl) {
-            if (l0) { mma16(acc[tl], a0h, w0h[k][tl]); mma16(acc[tl], a0h, w0l[k][tl]); mma16(acc[tl], a0l, w0h[k][tl]); }
+            // unconditional (see lstm2_persist8_kernel): v1 is zero while there is no h1
+            mma16(acc[tl], a0h, w0h[k][tl]); mma16(acc[tl], a0h, w0l[k][tl]); mma16(acc[tl], a0l, w0h[k][tl]);
             mma16(acc[2 + tl], a0h, w1ah[k][tl]); mma16(acc[2 + tl], a0h, w1al[k][tl]); mma16(acc[2 + tl], a0l, w1ah[k][tl]);
-            if (need1) { mma16(acc[2 + tl], a1h, w1bh[k][tl]); mma16(acc[2 + tl], a1h, w1bl[k][tl]); mma16(acc[2 + tl], a1l, w1bh[k][tl]); }
+            mma16(acc[2 + tl], a1h, w1bh[k][tl]); mma16(acc[2 + tl], a1h, w1bl[k][tl]); mma16(acc[2 + tl], a1l, w1bh[k][tl]);
           }
         }
       }
@@ -1208,28 +1315,35 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   int cus = 0, device = 0;
   if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
   const int max_clusters = cus / LP_SLICES < 4 ? cus / LP_SLICES : 4;
-  const int64_t ws_need = 256 + 2ll * 2 * 64 * 256 * 8;           // status word + granules of 4 clusters
-  if (persist && max_clusters >= 1 && dtype == PT_BF16 && d->H == LP_H && d->B * d->T * d->H * 2 >= ws_need) {
+  const int64_t ws_need = 512 + 2ll * 2 * 64 * 256 * 8;           // status word + census + granules of 64 rows
+  // bf16: 8-row clusters x 32 workgroups; needs the device's CUs to hold every workgroup of a launch at once
+  const int max_clusters8 = cus / L8_SLICES < 8 ? cus / L8_SLICES : 8;
+  if (persist && max_clusters8 >= 1 && dtype == PT_BF16 && d->H == LP_H && d->B * d->T * d->H * 2 >= ws_need) {
     // test hooks, read per call (never cached): a short spin bound and a workgroup that publishes wrong tags
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
-    const int rows_per_launch = 16 * max_clusters;
+    const int rows_per_launch = L8_ROWS * max_clusters8;
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
       LstmPersist q;
       q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
       const int64_t nb = d->B - b0 < rows_per_launch ? d->B - b0 : rows_per_launch;
-      q.clusters = (int)((nb + 15) / 16);
+      q.clusters = (int)((nb + L8_ROWS - 1) / L8_ROWS);
       q.x = (const bf16_t*)d->x; q.xg0 = (const bf16_t*)d->xg0; q.whh0 = (const bf16_t*)d->whh0; q.wcat1 = (const bf16_t*)d->wcat1;
       q.bias1 = d->bias1; q.out_elu = (bf16_t*)d->out_elu;
       q.err = status;
-      q.gx = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d->h0_seq) + 256);
       q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
       q.fault_slice = e_fault ? atoi(e_fault) : -1;
-      // tags of an earlier launch must not read as current: the granule block is cleared every launch; the status word only
-      // once per call, so that a timeout in any launch of the call stays visible (later launches then bail out at once)
+      // workspace: [0, 256) status word, [256, 512) census counters, then the granules.  Tags of an earlier launch must not read
+      // as current: census and granules are cleared every launch; the status word only once per call, so that a timeout in any
+      // launch of the call stays visible (later launches then bail out at once)
+      q.gx = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d->h0_seq) + 512);
+      q.census = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->h0_seq) + 256);
+      q.force_remote = pt_env_int("PT_LSTM_FORCE_REMOTE", 0);
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
-      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 8), s) != hipSuccess) return PT_ERR_LAUNCH;
-      hipLaunchKernelGGL(lstm2_persist_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
+      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 8), s) != hipSuccess) return PT_ERR_LAUNCH;
+      // always max_clusters8 x 32 workgroups, so that a 256-CU device sees 32 per XCD whatever the batch (workgroups of clusters
+      // without rows leave right after the census)
+      hipLaunchKernelGGL(lstm2_persist8_kernel, dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(256), 0, s, q);
       PT_LAUNCH_CHECK();
     }
     return PT_OK;

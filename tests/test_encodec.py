@@ -74,14 +74,17 @@ def test_hip_decoder_vs_oracle(dev, dtype, tol, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(5, 300), (20, 150), (70, 40)])
-def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, monkeypatch):
-    """bf16 decode at sizes that take the PERSISTENT LSTM (one launch for all T steps, weights resident in LDS, hidden state
-    exchanged between the cluster's 64 workgroups every step): 1, 2 and 4 + 1 clusters (70 rows = two launches), ragged last
-    cluster.  Checked against the CPU oracle (tolerance of test_hip_decoder_vs_oracle) and, tightly, against the same decoder
-    in f32 parity mode, which runs the step-per-launch LSTM."""
+@pytest.mark.parametrize("B,T,remote", [(5, 300, 0), (20, 150, 0), (70, 40, 0), (20, 150, 1), (70, 40, 1)])
+def test_persistent_lstm_decoder_vs_oracle_and_step_kernels(dev, B, T, remote, monkeypatch):
+    """bf16 decode at sizes that take the PERSISTENT LSTM (one launch for all T steps, weights resident in registers, hidden state
+    exchanged between the cluster's 32 workgroups every step): 1, 3 and 8 + 1 clusters of 8 rows (70 rows = two launches),
+    ragged last cluster; in the XCD-local form the census picks on a 256-CU device and (remote = 1) in the placement-independent
+    form that exchanges through memory.  Checked against the CPU oracle (tolerance of test_hip_decoder_vs_oracle) and,
+    tightly, against the same decoder in f32 mode."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
+    if remote:
+        monkeypatch.setenv("PT_LSTM_FORCE_REMOTE", "1")
     W = oe.random_weights(5)
     codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(B + T))
     got = EncodecDecoder(W, device=dev, dtype=torch.bfloat16).decode(codes.to(dev)).cpu()
@@ -333,14 +336,14 @@ def test_hip_encoder_bf16_embeddings(dev):
 @pytest.mark.gpu
 def test_persistent_lstm_timeout_raises_instead_of_returning_garbage(dev, monkeypatch):
     """VERDICT r02 / ADVICE r02: a lost hand-off of the persistent LSTM (its workgroups not all resident) used to return a garbage
-    waveform with PT_OK.  Force the timeout branch -- workgroup 5 publishes wrong tags, the spin bound is shrunk so that the
+    waveform with PT_OK.  Force the timeout branch -- the workgroup in role (cluster 0, slice 5) publishes wrong tags, the spin bound is shrunk so that the
     launch gives up after a few milliseconds -- and require decode() to RAISE; then decode again without the fault: the status
     word is cleared per call and the result is the good one."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
     W = oe.random_weights(5)
     dec = EncodecDecoder(W, device=dev, dtype=torch.bfloat16)
-    codes = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(3)).to(dev)   # 2 clusters, persistent form
+    codes = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(3)).to(dev)   # 3 clusters, persistent form
     good = dec.decode(codes).cpu()
     monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
     monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "5")
@@ -354,8 +357,8 @@ def test_persistent_lstm_timeout_raises_instead_of_returning_garbage(dev, monkey
 
 @pytest.mark.gpu
 def test_persistent_lstm_timeout_in_a_later_launch_of_the_call_is_sticky(dev, monkeypatch):
-    """70 rows = two launches (4 clusters + 1): the fault sits in workgroup 70, which exists only in the FIRST launch; the second
-    launch must not clear the word."""
+    """70 rows = two launches (8 clusters of 8 rows + 1): the fault sits in (cluster 2, slice 6) = role 70, which exists only in
+    the FIRST launch; the second launch must not clear the word."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
     dec = EncodecDecoder(oe.random_weights(5), device=dev, dtype=torch.bfloat16)

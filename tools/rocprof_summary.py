@@ -7,6 +7,10 @@
         correction follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB-like units of 1024 B as rocprofv3
         reports them here (checked against the fused AdamW kernel, whose traffic is 16 B read + 14 B written per parameter);
         FETCH_SIZE is DOUBLED (gfx950 tallies 128-B requests at 64 B).
+  rocprof_summary.py sq     <sq.db> <out.csv> [mark]
+        per-kernel sums of every counter of one multi-counter SQ pass (SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_VALU ...)
+        over one unit of work (training step by default; mark = rvq_kernelI6bf16_t for one decode) + each as a share of
+        SQ_WAVE_CYCLES when that counter is in the pass.
 """
 import collections
 import json
@@ -103,11 +107,45 @@ def pmc_decode(fetch_db, write_db, out):
         json.dump(res, f, indent=1)
 
 
+def sq(path, out, mark="adamw_kernel"):
+    db = sqlite3.connect(path)
+    kd, ks, pmc = _tables(db)
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    info = [t for t in tabs if "info_pmc" in t][0]
+    rows = db.execute(f"select d.start, s.kernel_name, d.dispatch_id, i.name, e.value from {pmc} e join {kd} d on e.event_id=d.event_id "
+                      f"join {ks} s on d.kernel_id=s.id join {info} i on e.pmc_id=i.id order by d.start").fetchall()
+    disp = collections.OrderedDict()
+    for st, n, did, c, v in rows:
+        disp.setdefault((st, did, n), collections.defaultdict(float))[c] += v
+    items = list(disp.items())
+    marks = [i for i, (k, _) in enumerate(items) if mark in k[2]]
+    seg = items[marks[-2] + 1:marks[-1] + 1] if mark == "adamw_kernel" else items[marks[1]:marks[2]]
+    agg, calls = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    for (_, _, n), cs in seg:
+        calls[n] += 1
+        for c, v in cs.items():
+            agg[n][c] += v
+    ctrs = sorted({c for a in agg.values() for c in a})
+    base = "SQ_WAVE_CYCLES" if "SQ_WAVE_CYCLES" in ctrs else None
+    names = sorted(agg, key=lambda n: -agg[n].get(base or ctrs[0], 0))
+    dm = _demangle(names)
+    with open(out, "w") as f:
+        f.write('"Name","Calls",' + ",".join(f'"{c}"' for c in ctrs) + ("," + ",".join(f'"{c}/WAVE_CYCLES"' for c in ctrs if c != base) if base else "") + "\n")
+        for n in names:
+            nm = re.sub(r"\(anonymous namespace\)::", "", dm[n])[:120]
+            line = f'"{nm}",{calls[n]},' + ",".join(f"{agg[n].get(c, 0):.0f}" for c in ctrs)
+            if base and agg[n].get(base, 0) > 0:
+                line += "," + ",".join(f"{agg[n].get(c, 0) / agg[n][base]:.3f}" for c in ctrs if c != base)
+            f.write(line + "\n")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "sq":
+        sq(*sys.argv[2:5])
     elif sys.argv[1] == "pmc_decode":
         pmc_decode(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
