@@ -352,20 +352,20 @@ __device__ unsigned long long lstm_trace_buf[4 * 64 * 8];
 constexpr int L8_UNITS = 16, L8_SLICES = 32, L8_ROWS = 8;
 constexpr int L8_RED_FLOATS = 4 * 8 * 4 * 32;                 // [wave][layer * 4 + gate][r][lane & 31]
 
+// One load per k-step and layer: the 16 granules of a k-step are one 128-byte line of the row, and the 64 lanes of a wave take the
+// lines of the 8 rows whole -- lane (li, g) reads chunk g + 4 (li >> 3) of row li & 7 (a 16-byte chunk = two granules).
 template <int AUX>
-__device__ __forceinline__ void l8_load16(u32x4_t (&v)[16], __amdgpu_buffer_rsrc_t grs, int voff0, int voff1, bool need1) {
+__device__ __forceinline__ void l8_load8(u32x4_t (&v)[8], __amdgpu_buffer_rsrc_t grs, int voff0, int voff1, bool need1) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    v[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, AUX);
-    v[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k + 64, 0, AUX);
-  }
+  for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, AUX);
   if (need1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[8 + 2 * k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, AUX);
-      v[8 + 2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k + 64, 0, AUX);
-    }
+    for (int k = 0; k < 4; ++k) v[4 + k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, AUX);
   }
+}
+// word of lane + 8 within its row of 16 lanes (DPP row_shl:8; lanes 8 .. 15 of a row read 0)
+__device__ __forceinline__ uint32_t l8_from_upper(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x108, 0xf, 0xf, true);
 }
 
 __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersist p) {
@@ -456,8 +456,6 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersis
   float xg_next[4];
 #pragma unroll
   for (int gi = 0; gi < 4; ++gi) xg_next[gi] = bf16_bits_to_f32(xin[gi]);
-  const bool loader = li < L8_ROWS;                        // lanes of the empty rows 8 .. 15 load nothing and multiply zeros
-
   for (int s = 0; s <= p.T; ++s) {
     const bool l0 = s < p.T, l1 = s >= 1;
     float xg[4];                                            // layer 1: xg[0] is the skip input
@@ -473,9 +471,13 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersis
     if (s >= 1) {
       const int par = (s - 1) & 1;
       const unsigned want = (unsigned)s;
-      const int row = L8_ROWS * c + (li & 7);
-      const int voff0 = (((par * 2 + 0) * rows + row) * 256 + 64 * wave + 2 * g) * 8;
-      const int voff1 = (((par * 2 + 1) * rows + row) * 256 + 64 * wave + 2 * g) * 8;
+      // Lane (li, g) reads chunk g + 4 (li >> 3) of row li & 7: one instruction covers the 128-byte lines of all 8 rows whole (as
+      // two half-line loads per k-step from the 32 lanes of rows 0 .. 7 a round was twice the requests into the L2).  Lanes
+      // li < 8 then hold slots 0 .. 3 of their A fragment and fetch slots 4 .. 7 from lane li + 8 (DPP); what lanes li >= 8 feed
+      // the MFMA is rows 8 .. 15 of the tile, which nobody reads.
+      const int row = L8_ROWS * c + (li & 7), chunk = g + 4 * (li >> 3);
+      const int voff0 = (((par * 2 + 0) * rows + row) * 256 + 64 * wave + 2 * chunk) * 8;
+      const int voff1 = (((par * 2 + 1) * rows + row) * 256 + 64 * wave + 2 * chunk) * 8;
       Frag<bf16_t> a0[4], a1[4];
       const bool need1 = s >= 2;
       int spin = 0;
@@ -484,19 +486,15 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersis
       const unsigned long long t_poll0 = __builtin_amdgcn_s_memtime();
 #endif
       for (;;) {
-        u32x4_t v[16];
+        u32x4_t v[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (u32x4_t){0u, want, 0u, want};
-        if (loader) {
-          // cross-XCD form: sc1 loads.  XCD-local form: nt loads -- both bypass the L1, but an sc1 load of a line that a peer has
-          // just dirtied in this L2 took ~3 300 cycles per round (the same 16 loads repeated right away: 1 400), an nt load
-          // is a plain L2 hit
-          if (local) l8_load16<2>(v, grs, voff0, voff1, need1);
-          else l8_load16<16>(v, grs, voff0, voff1, need1);
-        }
+        for (int i = 0; i < 8; ++i) v[i] = (u32x4_t){0u, want, 0u, want};
+        // cross-XCD form: sc1 loads.  XCD-local form: nt loads (both bypass the L1; an nt load is a plain L2 hit)
+        if (local) l8_load8<2>(v, grs, voff0, voff1, need1);
+        else l8_load8<16>(v, grs, voff0, voff1, need1);
         bool ok = true;                                     // a granule is {low word: two bf16, high word: tag}
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ok &= (v[i][1] == want) & (v[i][3] == want);
+        for (int i = 0; i < 8; ++i) ok &= (v[i][1] == want) & (v[i][3] == want);
         const bool all_ok = __all(ok);
 #if LSTM_TRACE
         if (spin == 0) t_first = __builtin_amdgcn_s_memtime() - t_poll0;
@@ -504,9 +502,9 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersis
         if (all_ok) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const u32x4_t w = {v[2 * k][0], v[2 * k][2], v[2 * k + 1][0], v[2 * k + 1][2]};
+            const u32x4_t w = {v[k][0], v[k][2], l8_from_upper(v[k][0]), l8_from_upper(v[k][2])};
             a0[k].v = __builtin_bit_cast(bf16x8_t, w);
-            const u32x4_t w1 = {v[8 + 2 * k][0], v[8 + 2 * k][2], v[8 + 2 * k + 1][0], v[8 + 2 * k + 1][2]};
+            const u32x4_t w1 = {v[4 + k][0], v[4 + k][2], l8_from_upper(v[4 + k][0]), l8_from_upper(v[4 + k][2])};
             a1[k].v = __builtin_bit_cast(bf16x8_t, w1);
           }
           LT_STAMP(1);
@@ -519,16 +517,17 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist8_kernel(const LstmPersis
           break;
         }
       }
+      // no conditions here: the last tick's layer-0 result is simply not used, and h1 is all zeros while there is none (tick 1)
+      // -- around conditional MFMAs hipcc copied the whole accumulator array (1 300 v_mov per tick); an accumulator comes
+      // round every fourth MFMA, not twice in a row (a dependent pair waits out the MFMA's latency)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-          // no conditions here: the last tick's layer-0 result is simply not used, and h1 is all zeros while there is none
-          // (tick 1) -- around conditional MFMAs hipcc copied the whole accumulator array (1 300 v_mov per tick)
-          mma16(acc[tl], a0[k], rw0[k][tl]);
-          mma16(acc[4 + tl], a0[k], rw1a[k][tl]);
-          mma16(acc[4 + tl], a1[k], rw1b[k][tl]);
-        }
+        for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0[k], rw0[k][tl]);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a0[k], rw1a[k][tl]);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a1[k], rw1b[k][tl]);
       }
     }
     LT_STAMP(2);
@@ -726,13 +725,12 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
           const u32x4_t h1 = {v1[4 * k][0], v1[4 * k + 1][0], v1[4 * k + 2][0], v1[4 * k + 3][0]};
           const u32x4_t o1 = {v1[4 * k][1], v1[4 * k + 1][1], v1[4 * k + 2][1], v1[4 * k + 3][1]};
           a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
-#pragma unroll
-          for (int tl = 0; tl < 2; ++tl) {
-            // unconditional (see lstm2_persist8_kernel): v1 is zero while there is no h1
-            mma16(acc[tl], a0h, w0h[k][tl]); mma16(acc[tl], a0h, w0l[k][tl]); mma16(acc[tl], a0l, w0h[k][tl]);
-            mma16(acc[2 + tl], a0h, w1ah[k][tl]); mma16(acc[2 + tl], a0h, w1al[k][tl]); mma16(acc[2 + tl], a0l, w1ah[k][tl]);
-            mma16(acc[2 + tl], a1h, w1bh[k][tl]); mma16(acc[2 + tl], a1h, w1bl[k][tl]); mma16(acc[2 + tl], a1l, w1bh[k][tl]);
-          }
+          // unconditional (see lstm2_persist8_kernel): v1 is zero while there is no h1; the four accumulators take turns
+          mma16(acc[0], a0h, w0h[k][0]); mma16(acc[1], a0h, w0h[k][1]); mma16(acc[2], a0h, w1ah[k][0]); mma16(acc[3], a0h, w1ah[k][1]);
+          mma16(acc[0], a0h, w0l[k][0]); mma16(acc[1], a0h, w0l[k][1]); mma16(acc[2], a0h, w1al[k][0]); mma16(acc[3], a0h, w1al[k][1]);
+          mma16(acc[0], a0l, w0h[k][0]); mma16(acc[1], a0l, w0h[k][1]); mma16(acc[2], a0l, w1ah[k][0]); mma16(acc[3], a0l, w1ah[k][1]);
+          mma16(acc[2], a1h, w1bh[k][0]); mma16(acc[3], a1h, w1bh[k][1]); mma16(acc[2], a1h, w1bl[k][0]); mma16(acc[3], a1h, w1bl[k][1]);
+          mma16(acc[2], a1l, w1bh[k][0]); mma16(acc[3], a1l, w1bh[k][1]);
         }
       }
     }
