@@ -110,6 +110,13 @@ __device__ __forceinline__ bf16x8_t a2_pack(const f32x16_t& x, int s) {
 // combine a per-lane value with the other 32-lane half's (lane l <-> l ^ 32).  v_permlane32_swap(vdst = x, src = x) swaps lanes
 // 32-63 of vdst with lanes 0-31 of src: the two results hold {own | other} and {other | own}, so their max / sum is the
 // combination in EVERY lane -- no select, no LDS.
+// max(a, b, c) as ONE v_max3_f32: written with fmaxf, hipcc emits a canonicalising v_max_f32 v, v beside each of the 31 maxima
+// of a 32-score row (48 instructions where 16 do)
+__device__ __forceinline__ float a2_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ float a2_half_max(float v) {
   const int x = __builtin_bit_cast(int, v);
   const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
