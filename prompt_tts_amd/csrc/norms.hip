@@ -683,7 +683,10 @@ int ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, 
   const int chunks = (int)((C / EPC + 63) / 64);
   const int rw = chunks <= 1 ? 4 : (chunks <= 2 ? 2 : 1);
   const int64_t want = (M + 4 * rw - 1) / (4 * rw);
-  dim3 grid((unsigned)(want < 1024 ? want : 1024));       // 8 rows per wave at M = 32768: amortises the dgamma/dbeta atomics
+  // <= 512 workgroups (16 rows per wave at M = 32768: amortises the dgamma / dbeta atomics; against 1024 workgroups: 27.2 -> 26.6 us
+  // there, 18.4 -> 16.2 us at M = 16384, 25.9 -> 19.2 us at M = 8192, C = 1024 -- tools/norm_probe.py)
+  static const int cap = pt_env_int("PT_LN_BWD_GRID", 512);
+  dim3 grid((unsigned)(want < cap ? want : cap));
 #define LN_B(MC) hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), grid, dim3(NT), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, M, (int)C, n_rep, rep_stride)
   if (chunks <= 1) LN_B(1); else if (chunks <= 2) LN_B(2); else if (chunks <= 4) LN_B(4); else return PT_ERR_SHAPE;
 #undef LN_B
