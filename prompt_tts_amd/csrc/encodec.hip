@@ -791,7 +791,7 @@ constexpr int TL_CIN = 64, TL_C = 32, TL_RIN = 64, TL_HALO = 5, TL_RI = 80, TL_R
 // LDS row strides of the intermediates: an MFMA result puts 16 DIFFERENT rows on the 16 lanes of a store group, all at the same
 // column, so a 64-byte row stride (a divisor of the 128-byte store bank window) is a 16-way conflict on every ds_write_b64;
 // 72 / 40 bytes spread consecutive rows over all banks (fragments are then read as two 8-byte halves)
-constexpr int TL_S64 = 72, TL_S32 = 40;
+constexpr int TL_S64 = 72, TL_S32 = 40, TL_W3S = 208;
 __device__ __forceinline__ bf16x8_t tl_frag(const char* p) {
   typedef __attribute__((ext_vector_type(2))) uint32_t u2;
   const u2 lo = *reinterpret_cast<const u2*>(p), hi = *reinterpret_cast<const u2*>(p + 8);
@@ -809,33 +809,36 @@ struct TailParams {
   int tiles_per_item;
 };
 
-__global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[TL_RI * TL_XSTRIDE + 3 * TL_RO * TL_S64 + TL_RO * TL_S32];
+__global__ __launch_bounds__(256, 3) void encodec_tail_kernel(const TailParams p) {
+  // Three workgroups per CU (12 waves): the kernel is a chain of short dependent phases, so what hides its latencies is the other
+  // workgroups.  That takes <= 168 registers per lane and <= 53 KiB of LDS: the k3 and final-conv weights (10 of the 30 B
+  // fragments) live in LDS, and Oute shares the input rows' storage (dead after phase B; equal size).
+  static_assert(TL_RI * TL_XSTRIDE == TL_RO * TL_S64, "Oute aliases Xin");
+  __shared__ __attribute__((aligned(16))) char smem[TL_RI * TL_XSTRIDE + 2 * TL_RO * TL_S64 + TL_RO * TL_S32 + 16 * TL_W3S + 7 * 64 + 64 * 4];
   char* Xin = smem;                                   // [80][144 B]: 64 channels + 16 B pad (bank spread)
   char* X1r = Xin + TL_RI * TL_XSTRIDE;               // [160][64 B] raw
   char* X1e = X1r + TL_RO * TL_S64;                       // [160][64 B] ELU
   char* C3e = X1e + TL_RO * TL_S64;                       // [160][32 B]
-  char* Oute = C3e + TL_RO * TL_S32;                      // [160][64 B]
+  char* W3s = C3e + TL_RO * TL_S32;                       // [16 columns][96 k] at a 208-byte row stride (16 rows -> 16 bank groups)
+  char* Wfs = W3s + 16 * TL_W3S;                          // [7 taps][32 k]: the single output channel of the final conv
+  float* Bts = reinterpret_cast<float*>(Wfs + 7 * 64);    // the transposed conv's 64 biases (read per row tile: 16 registers less)
+  char* Oute = Xin;                                       // [160][64 B], written in phase D
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   // ---- weights -> registers (B-operand fragments: output channel 16 nt + li, k = 32 ks + 8 g + j) ----
-  Frag<bf16_t> wt[4][4], w3[3], wf[2][2], wfin[7];
+  Frag<bf16_t> wt[4][4], wf[2][2];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) frag_load_global(wt[nt][ks], p.wt + (16 * nt + li) * 128 + 32 * ks + 8 * g);
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) frag_load_global(w3[ks], p.w3 + li * 96 + 32 * ks + 8 * g);
+  for (int q = tid; q < 16 * 12; q += 256) { const int row = q / 12, ch = q - row * 12;
+    *reinterpret_cast<u32x4_t*>(W3s + row * TL_W3S + 16 * ch) = *reinterpret_cast<const u32x4_t*>(p.w3 + row * 96 + 8 * ch); }
+  for (int q = tid; q < 7 * 4; q += 256) *reinterpret_cast<u32x4_t*>(Wfs + 16 * q) = *reinterpret_cast<const u32x4_t*>(p.wfin + 8 * q);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) frag_load_global(wf[nt][ks], p.wf + (16 * nt + li) * 64 + 32 * ks + 8 * g);
-#pragma unroll
-  for (int ks = 0; ks < 7; ++ks) { if (li == 0) frag_load_global(wfin[ks], p.wfin + 32 * ks + 8 * g); else frag_zero(wfin[ks]); }
-  float bt4[4][4], b34[4], bf4[2][4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bt4[nt][r] = p.bt[16 * nt + 4 * g + r];
+  float b34[4], bf4[2][4];
+  if (tid < 64) Bts[tid] = p.bt[tid];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { b34[r] = p.b3[4 * g + r]; bf4[0][r] = p.bf[4 * g + r]; bf4[1][r] = p.bf[16 + 4 * g + r]; }
   const float bfin = p.bfin[0];
@@ -891,9 +894,10 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {                                            // columns 16 nt + 4 g + r: rho = nt >> 1
         const int orow = 2 * i + (nt >> 1), co = 16 * (nt & 1) + 4 * g;
+        const f32x4_t bt4 = *reinterpret_cast<const f32x4_t*>(Bts + 16 * nt + 4 * g);
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = bf16_bits_to_f32(f32_to_bf16_bits(acc[nt][r] + bt4[nt][r]));   // the layer's bf16 output
+        for (int r = 0; r < 4; ++r) v[r] = bf16_bits_to_f32(f32_to_bf16_bits(acc[nt][r] + bt4[r]));   // the layer's bf16 output
         store4<bf16_t>(reinterpret_cast<bf16_t*>(X1r + orow * TL_S64) + co, v[0], v[1], v[2], v[3]);
         store4<bf16_t>(reinterpret_cast<bf16_t*>(X1e + orow * TL_S64) + co, elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3]));
       }
@@ -909,7 +913,9 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
         Frag<bf16_t> fa;
         if (sj >= 0 && sj < TL_RO) fa.v = tl_frag(X1e + sj * TL_S64 + 16 * g);
         else frag_zero(fa);
-        mma16(acc, w3[tap], fa);
+        Frag<bf16_t> wb;
+        wb.v = *reinterpret_cast<const bf16x8_t*>(W3s + li * TL_W3S + 64 * tap + 16 * g);
+        mma16(acc, wb, fa);
       }
       store4<bf16_t>(reinterpret_cast<bf16_t*>(C3e + j * TL_S32) + 4 * g, elu_f(acc[0] + b34[0]), elu_f(acc[1] + b34[1]),
                      elu_f(acc[2] + b34[2]), elu_f(acc[3] + b34[3]));
@@ -941,7 +947,9 @@ __global__ __launch_bounds__(256) void encodec_tail_kernel(const TailParams p) {
         Frag<bf16_t> fa;
         if (sj >= 0 && sj < TL_RO) fa.v = tl_frag(Oute + sj * TL_S64 + 16 * g);
         else frag_zero(fa);
-        mma16(acc, wfin[tap], fa);                                                // row 0 of D = the single output channel
+        Frag<bf16_t> wb;                                                          // row 0 of D = the single output channel
+        if (li == 0) wb.v = *reinterpret_cast<const bf16x8_t*>(Wfs + 64 * tap + 16 * g); else frag_zero(wb);
+        mma16(acc, wb, fa);
       }
       if (g == 0 && j >= j_lo && j < j_lo + 2 * TL_RIN && t < n_out) p.wav[(int64_t)b * n_out + t] = acc[0] + bfin;
     }

@@ -7,6 +7,10 @@
         correction follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB-like units of 1024 B as rocprofv3
         reports them here (checked against the fused AdamW kernel, whose traffic is 16 B read + 14 B written per parameter);
         FETCH_SIZE is DOUBLED (gfx950 tallies 128-B requests at 64 B).
+  rocprof_summary.py gaps   <trace.db> <out.json>
+        one training step (optimizer kernel to optimizer kernel) of a --kernel-trace run: wall time, time with at least one
+        kernel running (union of the dispatch intervals), with >= 2 running, and the idle gaps (count, total, histogram) --
+        the bubbles between dependent launches that no kernel tuning removes.
   rocprof_summary.py sq     <sq.db> <out.csv> [mark]
         per-kernel sums of every counter of one multi-counter SQ pass (SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_VALU ...)
         over one unit of work (training step by default; mark = rvq_kernelI6bf16_t for one decode) + each as a share of
@@ -107,6 +111,32 @@ def pmc_decode(fetch_db, write_db, out):
         json.dump(res, f, indent=1)
 
 
+def gaps(path, out):
+    db = sqlite3.connect(path)
+    kd, ks, _ = _tables(db)
+    rows = db.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
+    marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+    seg = rows[marks[-2] + 1:marks[-1] + 1]
+    t0, t1 = seg[0][0], max(r[1] for r in seg)
+    ev = sorted([(r[0], 1) for r in seg] + [(r[1], -1) for r in seg])
+    busy1 = busy2 = 0; depth = 0; last = t0; idle = []
+    for t, dlt in ev:
+        if depth >= 1: busy1 += t - last
+        if depth >= 2: busy2 += t - last
+        if depth == 0 and t > last: idle.append(t - last)
+        depth += dlt; last = t
+    hist = collections.Counter()
+    for g in idle:
+        hist["<1us" if g < 1000 else "1-2us" if g < 2000 else "2-5us" if g < 5000 else "5-10us" if g < 10000 else ">=10us"] += 1
+    res = {"source": "rocprofv3 --kernel-trace of bench.py; one training step, optimizer kernel to optimizer kernel",
+           "launches": len(seg), "wall_ms": (t1 - t0) / 1e6, "some_kernel_running_ms": busy1 / 1e6, "two_or_more_running_ms": busy2 / 1e6,
+           "idle_ms": sum(idle) / 1e6, "idle_gaps": len(idle), "idle_gap_histogram": dict(hist),
+           "sum_of_kernel_durations_ms": sum(r[1] - r[0] for r in seg) / 1e6}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
 def sq(path, out, mark="adamw_kernel"):
     db = sqlite3.connect(path)
     kd, ks, pmc = _tables(db)
@@ -144,6 +174,8 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "sq":
         sq(*sys.argv[2:5])
     elif sys.argv[1] == "pmc_decode":
