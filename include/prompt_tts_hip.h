@@ -355,8 +355,10 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *     REMOTE=1 forces that form).  Every workgroup of a launch must be resident at once; every wait is bounded;
  *   - persistent, f32-class (PT_F32, >= 64 CUs, exact_f32 == 0): clusters of 16 rows x 64 workgroups, bf16 x 3 products, the hi /
  *     lo weight fragments of a workgroup in registers and 16-byte granules, exchange through memory;
- *   - per step (exact f32, other H, small devices, PT_LSTM_PERSIST=0): T + 1 dependent launches (layer 0 step s beside layer 1
- *     step s - 1).
+ *   - persistent, exact f32 (PT_F32, exact_f32 != 0): that kernel on v_mfma_f32_16x16x4_f32 with the f32 hidden values themselves
+ *     in the granules (the Encodec ENCODER: 15.8 -> 9.3 ms per 32 x 900 frames against the per-step kernels);
+ *   - per step (other H, small devices or inputs, PT_LSTM_PERSIST=0 / PT_LSTM_PERSIST_EXACT=0): T + 1 dependent launches (layer 0
+ *     step s beside layer 1 step s - 1).
  * `status`: device pointer to ONE 32-bit word owned by the caller, or NULL.  The call clears it on the stream; after the call
  * has completed on the stream, 0 = ok and non-zero = a hand-off of the persistent form timed out (out_elu is then INVALID:
  * copy the word back -- e.g. to pinned memory on the same stream -- and check it before using the result).  With NULL the word is
@@ -366,7 +368,7 @@ typedef struct pt_lstm2_desc {
   const void* x; const void* xg0; const void* whh0; const void* wcat1; const float* bias1;
   void* h0_seq; void* h1_seq; float* c0; float* c1; void* out_elu;
   void* status;
-  int64_t exact_f32;     /* PT_F32: != 0 = always the per-step kernels on the exact f32 MFMA (the Encodec ENCODER, whose output
+  int64_t exact_f32;     /* PT_F32: != 0 = the exact f32 MFMA, persistent or per step (the Encodec ENCODER, whose output
                             feeds integer code decisions); 0 = the persistent f32-class form where it applies (bf16 x 3 products:
                             ~1e-5 relative, for the decoder's 1e-3 waveform bound) */
 } pt_lstm2_desc;

@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 3)) void attn2_fwd_kernel(cons
     // row maximum over this tile (32 values per lane, then the other lane half)
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
+#ifdef A2_NO_MAX3
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s[0][e], s[1][e]));
+#else
     for (int e = 1; e < 16; ++e) mx = a2_max3(mx, s[0][e], s[1][e]);
+#endif
     mx = a2_half_max(mx);
     // first tile: adopt the maximum; later: refresh only if some row outgrew the reference by 2^THR (wave-uniform branch)
     const bool refresh = t == 0 || __any(mx > A2_RESCALE_THR);

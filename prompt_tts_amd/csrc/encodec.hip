@@ -624,6 +624,7 @@ __device__ __forceinline__ void split_bf16x8(const float* w, Frag<bf16_t>& hi, F
   }
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersist3 p) {
   __shared__ float red[4 * 4 * 4 * 64];
   __shared__ int abort_flag;
@@ -635,7 +636,9 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
   // ---- resident weights as register B fragments: column lc = 16 tl + li (gate 2 tl + (li >> 3), unit li & 7); slot j of lane
   //      (li, g) in k-step ks = hidden unit 32 ks + 8 (j >> 1) + 2 g + (j & 1), the order the granule loads deliver the A operand;
   //      this wave's k-steps: layer 0: 4 wave + k; layer 1: 4 wave + k (h0 part) and 16 + 4 wave + k (h1 part) ----
+  //      EXACT: the same slots hold the f32 weights themselves (one v_mfma_f32_16x16x4_f32 per pair of slots j, j + 4 ... see below)
   Frag<bf16_t> w0h[4][2], w0l[4][2], w1ah[4][2], w1al[4][2], w1bh[4][2], w1bl[4][2];
+  float x0[4][2][8], x1a[4][2][8], x1b[4][2][8];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -643,9 +646,19 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
       const int lc = 16 * tl + li;
       const int64_t grow = (int64_t)(lc >> 3) * LP_H + LP_UNITS * u + (lc & 7);
       const int k0 = 32 * (4 * wave + k) + 2 * g;
-      split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
-      split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
-      split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], w1bl[k][tl]);
+      if constexpr (EXACT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = 8 * (j >> 1) + (j & 1);
+          x0[k][tl][j] = p.whh0[grow * LP_H + k0 + o];
+          x1a[k][tl][j] = p.wcat1[grow * 2 * LP_H + k0 + o];
+          x1b[k][tl][j] = p.wcat1[grow * 2 * LP_H + LP_H + k0 + o];
+        }
+      } else {
+        split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
+        split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
+        split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], w1bl[k][tl]);
+      }
     }
   // ---- gate-math role of this thread: (layer, batch row, unit) ----
   const int layer = tid >> 7, b = (tid >> 3) & 15, jj = tid & 7;
@@ -715,7 +728,24 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
           break;
         }
       }
-      if (!aborted) {
+      if constexpr (EXACT) {
+        // exact f32 (the encoder: its embeddings feed integer code decisions): a granule carries two f32 hidden values, slot
+        // j = 2 i + c of k-block k is word c of load i, and four lanes g make one K = 4 step of v_mfma_f32_16x16x4_f32
+        if (!aborted) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float a0 = __uint_as_float(v0[4 * k + (j >> 1)][j & 1]), a1 = __uint_as_float(v1[4 * k + (j >> 1)][j & 1]);
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][0][j], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][1][j], acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x1a[k][0][j], acc[2], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x1a[k][1][j], acc[3], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1b[k][0][j], acc[2], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1b[k][1][j], acc[3], 0, 0, 0);
+            }
+        }
+      } else if (!aborted) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           Frag<bf16_t> a0h, a0l, a1h, a1l;
@@ -759,12 +789,14 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
     }
     if (s < p.T) {
       // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
+      //          (EXACT: {f32 of unit jj, f32 of unit jj + 1, tag, tag})
       const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
       const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
       const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
+      const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
       if ((jj & 1) == 0) {
         const unsigned tag = (unsigned)(s + 1) + ((int)blockIdx.x == p.fault_slice ? 0x40000000u : 0u);
-        const u32x4_t gran = {hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), hn_o, tag, tag} : (u32x4_t){hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
         u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + 16 * c + b)) * 256 + (LP_UNITS * u + jj) / 2;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
       }
@@ -1357,7 +1389,9 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   // f32 (the reference's precision): the same persistent plan with bf16 x 3 products and register-resident hi / lo weights
   static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
   const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
-  if (persist && persist3 && !d->exact_f32 && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
+  // exact_f32: the same kernel on the exact f32 MFMA (PT_LSTM_PERSIST_EXACT=0: the per-step kernels)
+  const int persist_exact = pt_env_int("PT_LSTM_PERSIST_EXACT", 1);      // read per call: tests compare the two forms
+  if (persist && (d->exact_f32 ? persist_exact : persist3) && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = 16 * max_clusters;
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
@@ -1374,7 +1408,8 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
-      hipLaunchKernelGGL(lstm2_persist3_kernel, dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
+      if (d->exact_f32) hipLaunchKernelGGL((lstm2_persist3_kernel<true>), dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
+      else hipLaunchKernelGGL((lstm2_persist3_kernel<false>), dim3((unsigned)(q.clusters * LP_SLICES)), dim3(256), 0, s, q);
       PT_LAUNCH_CHECK();
     }
     return PT_OK;

@@ -106,7 +106,7 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None,
     ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = x.data_ptr(), xg0.data_ptr(), w_hh0.data_ptr(), wcat1.data_ptr(), bias1.data_ptr()
     ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
     ld.status = st.ptr()
-    ld.exact_f32 = int(exact_f32)      # the encoder: its embeddings feed integer code decisions -> exact f32 MFMA, per-step kernels
+    ld.exact_f32 = int(exact_f32)      # the encoder: its embeddings feed integer code decisions -> exact f32 MFMA
     check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
     st.fetch()
     return ze, st

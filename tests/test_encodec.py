@@ -308,6 +308,30 @@ def test_hip_encoder_vs_oracle(dev, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(20, 60), (70, 24)])
+def test_exact_f32_persistent_lstm_of_the_encoder(dev, B, T, monkeypatch):
+    """The encoder's LSTM at sizes that take the PERSISTENT exact-f32 form (v_mfma_f32_16x16x4_f32, f32 hidden values in the
+    granules; 2 clusters; 4 + 1 clusters in two launches): embeddings against the per-step kernels (same arithmetic, another
+    summation order: 1e-5 of the peak) and against the CPU oracle (1e-3), codes against the oracle's."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecEncoder
+    W = oe.random_encoder_weights(6)
+    wav = torch.randn(B, 1, 320 * T, generator=torch.Generator().manual_seed(B + T)) * 0.5
+    enc = EncodecEncoder(W, device=dev, dtype=torch.float32)
+    emb, b, t = enc.embeddings(wav.to(dev))
+    monkeypatch.setenv("PT_LSTM_PERSIST_EXACT", "0")
+    emb_step, _, _ = enc.embeddings(wav.to(dev))
+    monkeypatch.delenv("PT_LSTM_PERSIST_EXACT")
+    peak = float(emb_step.abs().max())
+    assert float((emb - emb_step).abs().max()) < 1e-5 * peak, float((emb - emb_step).abs().max()) / peak
+    want = oe.encoder_embeddings(wav[:3], W)
+    got = emb.view(B, T, 128)[:3].permute(0, 2, 1).cpu()
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-3
+    codes = enc.quantize(emb, b, t).cpu()
+    assert float((codes[:3] == oe.encode(wav[:3], W)).float().mean()) > 0.97
+
+
+@pytest.mark.gpu
 def test_hip_encoder_causal_and_batch_independent(dev):
     """Size-independent properties at a longer length: items are independent; a prefix encodes to the prefix of the codes."""
     from oracle import encodec as oe
