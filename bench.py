@@ -261,6 +261,18 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
         e1.record(); torch.cuda.synchronize()
         stage_ms[k] = e0.elapsed_time(e1) / iters
     assert sampled.shape == codes.shape and int(sampled.min()) >= 0 and int(sampled.max()) < bins
+    # autoregressive token generation (build-defined, SURVEY 8a'): ARCodecDecoder.generate, one frame per step against its K/V
+    # cache -- a launch-bound loop: launch by launch, and with the decode step captured as a HIP graph and replayed
+    def ar_ms_per_frame(graph, frames=48):
+        from prompt_tts_amd.ar import ARCodecDecoder
+        torch.manual_seed(3)
+        ar = ARCodecDecoder(512, 4, 8, 1024, 8, max_frames=frames, dtype=dtype).to(dev)
+        ctx = (torch.randn(prompts, 64, 512, generator=torch.Generator().manual_seed(9)) * 0.5).to(dev)
+        ar.generate(ctx, 8, graph=graph); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ar.generate(ctx, frames, graph=graph); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames * 1e3
+    ar_eager, ar_graph = ar_ms_per_frame(False), ar_ms_per_frame(True)
     out = {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
            "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
            "lstm_ms": lstm_ms, "lstm_steps_per_s": 2 * T / (lstm_ms * 1e-3) if lstm_ms else None,
@@ -275,6 +287,9 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
                                 "null if absent; algorithmic I/O = codes in + waveform out + weights once"},
            "hbm_view": hbm,
            "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
+           "ar_generate": {"what": "ARCodecDecoder (d 512, 4 layers, 8 codebooks) greedy generate, %d prompts, ms per frame" % prompts,
+                           "launch_by_launch": ar_eager, "hip_graph_replay": ar_graph,
+                           "codec_tokens_per_s_graph": prompts * 8 / (ar_graph * 1e-3)},
            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),
            "weights": "seeded random (no checkpoint offline)"}
     # the same workload at the REFERENCE's precision (decode_codec.py decodes in fp32), and what each dtype costs in accuracy

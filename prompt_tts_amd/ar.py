@@ -45,6 +45,9 @@ class LogitsHead(nn.Module):
         return E.linear_fwd(h, st.w(self.proj.weight), st.f(self.proj.bias), out_f32=out_f32)
 
 
+AR_GRAPH = __import__("os").environ.get("PT_AR_GRAPH", "1") != "0"     # capture the decode step of generate() as a HIP graph
+
+
 class ARCodecDecoder(nn.Module):
     def __init__(self, d_model=512, n_layers=4, n_q=8, bins=1024, heads=8, cross_attention_dim=None, max_frames=1024,
                  dtype=torch.bfloat16):
@@ -121,7 +124,10 @@ class ARCodecDecoder(nn.Module):
         else:
             q, k, v = (E.linear_fwd(n1, st.w(p.weight)) for p in (a1.to_q, a1.to_k, a1.to_v))
         kc, vc = cache
-        kc[:, t] = k; vc[:, t] = v                                           # append this frame's key / value
+        if torch.is_tensor(t):                                               # device-resident frame index (captured decode step)
+            kc.index_copy_(1, t, k.unsqueeze(1)); vc.index_copy_(1, t, v.unsqueeze(1))
+        else:
+            kc[:, t] = k; vc[:, t] = v                                       # append this frame's key / value
         Tm = kc.shape[1]
         o = torch.empty(B, C, dtype=h.dtype, device=h.device)
         lse = torch.empty(B, self.heads, 1, dtype=torch.float32, device=h.device)
@@ -134,9 +140,12 @@ class ARCodecDecoder(nn.Module):
         return out
 
     @torch.no_grad()
-    def generate(self, ctx, T, k=1, uniforms=None, temperature=1.0):
+    def generate(self, ctx, T, k=1, uniforms=None, temperature=1.0, graph=None):
         """ctx (B, S, d_ctx) -> codes (B, n_q, T) int64.  k = 1: greedy argmax; k > 1: top-k sampling, one INJECTED uniform per
-        (frame, prompt, codebook): uniforms (T, B * n_q) f32 in [0, 1)."""
+        (frame, prompt, codebook): uniforms (T, B * n_q) f32 in [0, 1).
+        graph (default: PT_AR_GRAPH, on): frames 0 and 1 run launch by launch, then ONE decode step -- ~25 launches per layer of a
+        few microseconds each, a launch-bound loop -- is captured as a HIP graph whose frame index, K/V length, previous codes and
+        uniforms row live on the device, and replayed for every remaining frame; same kernels in the same order, same codes."""
         st = self.store
         st.ensure_shadow_fresh()
         B, S = ctx.shape[0], ctx.shape[1]
@@ -150,8 +159,11 @@ class ARCodecDecoder(nn.Module):
                   for _ in self.blocks]
         codes = torch.zeros(B, self.n_q, T, dtype=torch.int64, device=dev)
         prev = torch.zeros(B, self.n_q, 1, dtype=torch.int64, device=dev)
+        if graph is None:
+            graph = AR_GRAPH
+        n_eager = T if not graph or T < 4 else 2
         with E.cross_kv_cache():
-            for t in range(T):
+            for t in range(n_eager):
                 h = self._embed(st, prev, t0=t)
                 kv_len = torch.full((B,), t + 1, dtype=torch.int32, device=dev)
                 for blk, cache in zip(self.blocks, caches):
@@ -161,4 +173,33 @@ class ARCodecDecoder(nn.Module):
                 idx = ops.sample_topk(logits, k=k, uniforms=uniforms[t].contiguous() if k > 1 else None, temperature=temperature)
                 prev = idx.view(B, self.n_q, 1)
                 codes[:, :, t] = prev[:, :, 0]
+            if n_eager < T:
+                # ---- the decode step with every per-frame quantity on the device ----
+                t_dev = torch.full((1,), n_eager, dtype=torch.int64, device=dev)
+                kv_len = torch.full((B,), n_eager + 1, dtype=torch.int32, device=dev)
+                prev_buf = prev.contiguous().clone()
+                pos = self._pos.to(st.dtype)
+                emb = st.w(self.code_embedding)
+
+                def step():
+                    x = torch.empty(B, self.d, dtype=st.dtype, device=dev)
+                    ops.rvq_decode(prev_buf, emb, x, B, self.n_q, 1, self.bins, self.d)
+                    h = (x + pos.index_select(0, t_dev)).contiguous()
+                    for blk, cache in zip(self.blocks, caches):
+                        h = self._block_step(st, blk, h, cache, t_dev, kv_len, ctx2, B, S)
+                    n, _ = E.layernorm_fwd(h, st.f(self.norm_out.weight), st.f(self.norm_out.bias))
+                    logits = self.head.fwd(st, n).view(B * self.n_q, self.bins)
+                    u = uniforms.index_select(0, t_dev).view(-1) if k > 1 else None
+                    idx = ops.sample_topk(logits, k=k, uniforms=u, temperature=temperature)
+                    prev_buf.copy_(idx.view(B, self.n_q, 1))
+                    codes.index_copy_(2, t_dev, prev_buf)
+                    t_dev.add_(1); kv_len.add_(1)
+
+                if k > 1:
+                    uniforms = uniforms.contiguous()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step()
+                for _ in range(n_eager, T):
+                    g.replay()
         return codes

@@ -93,3 +93,19 @@ def test_generate_with_kv_cache_equals_teacher_forced_decisions(dev, k):
     # the device's own teacher-forced pass agrees with its incremental pass
     lg = m(codes.to(dev), ctx.to(dev)).cpu()
     assert relerr(lg, logits) < 1e-3
+
+
+@pytest.mark.parametrize("k,dtype", [(1, torch.float32), (8, torch.bfloat16)])
+def test_generate_graph_replay_equals_launch_by_launch(dev, k, dtype):
+    """generate() captures ONE decode step (frame index, K/V length, previous codes, uniforms row on the device) as a HIP graph and
+    replays it; launch by launch (graph=False) the same kernels run in the same order: the codes are identical."""
+    _, m = _pair(dev, dtype, seed=5)
+    g = torch.Generator().manual_seed(7)
+    B, T, S = 3, 40, 24
+    ctx = torch.randn(B, S, 256, generator=g).to(dev)
+    u = torch.rand(T, B * 4, generator=g).to(dev)
+    a = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=True)
+    b = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=False)
+    assert a.shape == (B, 4, T) and torch.equal(a, b) and len(torch.unique(a)) > 10
+    c = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=True)      # a second capture in the same process
+    assert torch.equal(a, c)
