@@ -99,9 +99,20 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
     }
   }
   const int K1 = p.taps * p.cin;
+  // which tap / input channel a lane's k-slice of k-step ks reads does not depend on the row: one division per k-step and
+  // kernel, not one per fragment (with the two 64-bit row divisions below per row tile, index arithmetic was ~1 400 vector
+  // instructions per 64-row block against 1 344 cycles of MFMA in the 7-tap x3 kernel)
+  int tap_of[KS], ci_of[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = 32 * ks + 8 * g;
+    tap_of[ks] = k0 < K1 ? k0 / p.cin : 0; ci_of[ks] = k0 - tap_of[ks] * p.cin;
+  }
   const int64_t nblk = (p.M + 63) / 64;
   for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < nblk; blk += (int64_t)gridDim.x * 4) {
     const int64_t r0 = blk * 64;
+    // item / row of the block's first row (wave-uniform), then consecutive rows step through the items
+    const int64_t b_first = r0 / p.n_rows; const int n_first = (int)(r0 - b_first * p.n_rows);
     f32x4_t acc[4][NT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -111,14 +122,16 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
     for (int rt = 0; rt < 4; ++rt) {
       const int64_t m = r0 + 16 * rt + li;
       const bool mok = m < p.M;
-      const int64_t b = mok ? m / p.n_rows : 0; const int n = mok ? (int)(m - b * p.n_rows) : 0;
+      int64_t b = b_first; int n = n_first + 16 * rt + li;
+      while (n >= p.n_rows) { n -= p.n_rows; ++b; }
+      if (!mok) { b = 0; n = 0; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k0 = 32 * ks + 8 * g;
         Frag<T> fa;
         bool have = false; int elu = 0;
         if (mok && k0 < K1) {
-          const int tap = k0 / p.cin, ci = k0 - tap * p.cin;
+          const int tap = tap_of[ks], ci = ci_of[ks];
           int ns; bool ok;
           if (p.rowmap == PT_MAP_CAUSAL_REFLECT) { const int v = n + tap - (p.taps - 1); ns = v < 0 ? -v : v; ok = ns < p.n_rows; }
           else if (p.rowmap == PT_MAP_STRIDED_REFLECT) { const int v = n * p.stride + tap - (p.taps - p.stride); ns = v < 0 ? -v : v; ok = ns < p.n_in; }
@@ -173,7 +186,209 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvParams p) {
   }
 }
 
+// ---- row-streaming conv, input rows staged through LDS -----------------------------------------------------------------------
+// A k-tap conv reads every input row `taps` times (taps / stride for the strided maps).  Fetched straight from global memory by
+// every fragment, those re-reads come from the L2 -- 20 waves x 9 KiB of live rows per CU do not stay in a 32 KiB L1: the 7-tap
+// final conv of the f32 decoder moved 19 GB through the L2 for 2.7 GB of input (2.65 ms).  Here a wave stages the input rows of
+// its block ONCE (whole rows, coalesced) into its own slice of LDS -- with the input ELU and, for X3, the hi / lo split applied
+// there, once per element instead of once per tap -- and the k-steps read their fragments from LDS.  A block = 16 RT output
+// rows; blocks that touch an item edge (reflect / zero padding, two items) take the global-memory path of rowconv_kernel.
+// LDS image per wave: [planes][rows][cin elements + 8 pad]; planes: X3 = {hi, lo} bf16, else one of T.
+template <typename T, int NT, int KS, bool X3, int RT>
+__global__ __launch_bounds__(256, 2) void rowconv_staged_kernel(const RowConvParams p, const int rows_cap, const int cshift) {
+  extern __shared__ __attribute__((aligned(16))) char rc_smem[];
+  using E = typename std::conditional<X3, bf16_t, T>::type;          // LDS element
+  constexpr int PL = X3 ? 2 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const int row_bytes = (p.cin + 8) * (int)sizeof(E), plane_bytes = rows_cap * row_bytes;
+  char* img = rc_smem + wave * PL * plane_bytes;
+  using WF = typename std::conditional<X3, FragX3, Frag<T>>::type;
+  WF wf[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = 16 * nt + li;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag<T> w;
+      // (no second input in this kernel: k-slices past taps x cin get ZERO weights, so the staged path may read any finite
+      // activation for them and needs no per-fragment condition)
+      if (n < p.N && 32 * ks + 8 * g < p.taps * p.cin) frag_load_global(w, reinterpret_cast<const T*>(p.w) + (int64_t)n * p.ldw + 32 * ks + 8 * g);
+      else frag_zero(w);
+      if constexpr (X3) wf[nt][ks] = split_x3(w); else wf[nt][ks] = w;
+    }
+  }
+  const int K1 = p.taps * p.cin;
+  int tap_of[KS], ci_of[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = 32 * ks + 8 * g;
+    tap_of[ks] = k0 < K1 ? k0 / p.cin : 0; ci_of[ks] = k0 < K1 ? k0 - tap_of[ks] * p.cin : 0;
+  }
+  const int stride = p.rowmap == PT_MAP_STRIDED_REFLECT ? p.stride : 1;
+  const int back_rows = p.rowmap == PT_MAP_STRIDED_REFLECT ? p.taps - p.stride : p.taps - 1;    // input rows before the block's first
+  const int cpr = p.cin >> 3;                                         // 8-element chunks per row (a power of two: cshift)
+  constexpr int BR = 16 * RT;
+  const int64_t nblk = (p.M + BR - 1) / BR;
+  for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < nblk; blk += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = blk * BR;
+    const int64_t b_first = r0 / p.n_rows; const int n_first = (int)(r0 - b_first * p.n_rows);
+    const int in_lo = n_first * stride - back_rows, in_cnt = (BR - 1) * stride + p.taps;
+    const bool staged = r0 + BR <= p.M && n_first + BR <= p.n_rows && in_lo >= 0 && in_lo + in_cnt <= p.n_in;     // wave-uniform
+    if (staged) {
+      const T* src = reinterpret_cast<const T*>(p.x) + (b_first * p.n_in + in_lo) * p.ldx;
+      for (int q = lane; q < in_cnt * cpr; q += 64) {
+        const int row = q >> cshift, c8 = q & (cpr - 1);
+        Frag<T> f;
+        frag_load_global(f, src + (int64_t)row * p.ldx + 8 * c8);
+        if (p.elu_x) frag_elu<T>(f);
+        char* dst = img + row * row_bytes + c8 * 8 * (int)sizeof(E);
+        if constexpr (X3) {
+          const FragX3 x = split_x3(f);
+          *reinterpret_cast<bf16x8_t*>(dst) = x.hi; *reinterpret_cast<bf16x8_t*>(dst + plane_bytes) = x.lo;
+        } else if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<bf16x8_t*>(dst) = f.v;
+        } else {
+          *reinterpret_cast<f32x4_t*>(dst) = (f32x4_t){f.v[0], f.v[1], f.v[2], f.v[3]};
+          *reinterpret_cast<f32x4_t*>(dst + 16) = (f32x4_t){f.v[4], f.v[5], f.v[6], f.v[7]};
+        }
+      }
+    }
+    f32x4_t acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4_t){0, 0, 0, 0};
+    if (staged) {
+      // straight-line: 2 (X3) / 1-2 LDS reads and the MFMAs per (row tile, k-step).  With four column tiles the row tiles stay a
+      // loop: fully unrolled, hipcc hoists every LDS read of the block to the top and the kernel spills at 256 registers
+      constexpr int RT_UNROLL = NT >= 4 ? 1 : RT;
+#pragma unroll RT_UNROLL
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int tap = tap_of[ks];
+          const int lrow = p.rowmap == PT_MAP_BACK ? 16 * rt + li + back_rows - tap : (16 * rt + li) * stride + tap;
+          const char* a = img + lrow * row_bytes + ci_of[ks] * (int)sizeof(E);
+          if constexpr (X3) {
+            FragX3 xa;
+            xa.hi = *reinterpret_cast<const bf16x8_t*>(a); xa.lo = *reinterpret_cast<const bf16x8_t*>(a + plane_bytes);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma16x3(acc[rt][nt], wf[nt][ks], xa);
+          } else {
+            Frag<T> fa;
+            if constexpr (sizeof(T) == 2) {
+              fa.v = *reinterpret_cast<const bf16x8_t*>(a);
+            } else {
+              const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(a), hi = *reinterpret_cast<const f32x4_t*>(a + 16);
+              fa.v[0] = lo[0]; fa.v[1] = lo[1]; fa.v[2] = lo[2]; fa.v[3] = lo[3]; fa.v[4] = hi[0]; fa.v[5] = hi[1]; fa.v[6] = hi[2]; fa.v[7] = hi[3];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma16(acc[rt][nt], wf[nt][ks], fa);
+          }
+        }
+    } else {
+      // a block at an item edge: the fragments come from global memory, with the padding rules of the row map
+      for (int rt = 0; rt < RT; ++rt) {
+        const int64_t m = r0 + 16 * rt + li;
+        const bool mok = m < p.M;
+        int64_t b = b_first; int n = n_first + 16 * rt + li;
+        while (n >= p.n_rows) { n -= p.n_rows; ++b; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k0 = 32 * ks + 8 * g;
+          Frag<T> fa;
+          bool have = false;
+          if (mok && k0 < K1) {
+            const int tap = tap_of[ks], ci = ci_of[ks];
+            int ns; bool ok;
+            if (p.rowmap == PT_MAP_CAUSAL_REFLECT) { const int v = n + tap - (p.taps - 1); ns = v < 0 ? -v : v; ok = ns < p.n_rows; }
+            else if (p.rowmap == PT_MAP_STRIDED_REFLECT) { const int v = n * p.stride + tap - (p.taps - p.stride); ns = v < 0 ? -v : v; ok = ns < p.n_in; }
+            else { ns = n - tap; ok = ns >= 0; }                                   // PT_MAP_BACK
+            if (ok) { frag_load_global(fa, reinterpret_cast<const T*>(p.x) + (b * p.n_in + ns) * p.ldx + ci); have = true; }
+          }
+          if (!have) frag_zero(fa);
+          else if (p.elu_x) frag_elu<T>(fa);
+          f32x4_t accr[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) accr[nt] = (f32x4_t){0, 0, 0, 0};
+          if constexpr (X3) {
+            const FragX3 xa = split_x3(fa);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma16x3(accr[nt], wf[nt][ks], xa);
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma16(accr[nt], wf[nt][ks], fa);
+          }
+          // (rt is a run-time index here -- this path is rare and kept small: add into the tile it belongs to)
+#pragma unroll
+          for (int q = 0; q < RT; ++q)
+            if (q == rt) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[q][nt] += accr[nt];
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int64_t m = r0 + 16 * rt + li;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = 16 * nt + 4 * g;
+        if (n0 >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + r;
+          float x = acc[rt][nt][r] + ((p.bias && n < p.N) ? p.bias[n] : 0.f);
+          v[r] = p.act == 1 ? elu_f(x) : x;
+        }
+        if (n0 + 3 < p.N) {
+          if (p.y_f32) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.y) + m * p.ldy + n0) = (f32x4_t){v[0], v[1], v[2], v[3]};
+          else store4<T>(reinterpret_cast<T*>(p.y) + m * p.ldy + n0, v[0], v[1], v[2], v[3]);
+        } else {
+          for (int r = 0; r < 4 && n0 + r < p.N; ++r) {
+            if (p.y_f32) reinterpret_cast<float*>(p.y)[m * p.ldy + n0 + r] = v[r];
+            else reinterpret_cast<T*>(p.y)[m * p.ldy + n0 + r] = from_f32<T>(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int NT, int KS, bool X3, int RT> int launch_rowconv_staged(const RowConvParams& p, int cshift, hipStream_t s) {
+  const int stride = p.rowmap == PT_MAP_STRIDED_REFLECT ? p.stride : 1;
+  const int rows_cap = (16 * RT - 1) * stride + p.taps;
+  const int esz = X3 ? 2 : (int)sizeof(T);
+  const size_t lds = (size_t)4 * (X3 ? 2 : 1) * rows_cap * (p.cin + 8) * esz;
+  if (lds > 64 * 1024) return PT_ERR_SHAPE;                          // the caller falls back
+  int64_t blocks = (p.M + 64 * RT - 1) / (64 * RT);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((rowconv_staged_kernel<T, NT, KS, X3, RT>), dim3((unsigned)blocks), dim3(256), lds, s, p, rows_cap, cshift);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
 template <typename T, int NT, int KS> int launch_rowconv(const RowConvParams& p, hipStream_t s) {
+  // inputs read more than once (taps > stride), whole power-of-two rows, enough rows per item: the LDS-staged kernel
+  static const int staged_on = pt_env_int("PT_ROWCONV_STAGED", 1);
+  const int stride = p.rowmap == PT_MAP_STRIDED_REFLECT ? p.stride : 1;
+  if (staged_on && (!p.x2 || p.cin2 == 0) && p.taps > stride && (p.cin & (p.cin - 1)) == 0 && p.cin >= 8 && p.cin <= 64 && p.n_rows >= 256 && p.M >= 4096) {
+    int cshift = 0;
+    while ((8 << cshift) < p.cin) ++cshift;
+    int st = PT_ERR_SHAPE;
+    // 64-row blocks where the weight fragments leave room for four row tiles of accumulators (and the rows fit LDS), else 32
+    constexpr bool big = NT * KS <= 8;
+    if constexpr (std::is_same<T, float>::value) {
+      if (p.x3) st = big && p.cin <= 32 ? launch_rowconv_staged<T, NT, KS, true, 4>(p, cshift, s) : launch_rowconv_staged<T, NT, KS, true, 2>(p, cshift, s);
+      else st = big && p.cin <= 16 ? launch_rowconv_staged<T, NT, KS, false, 4>(p, cshift, s) : launch_rowconv_staged<T, NT, KS, false, 2>(p, cshift, s);
+    } else {
+      st = big && p.cin <= 32 ? launch_rowconv_staged<T, NT, KS, false, 4>(p, cshift, s) : launch_rowconv_staged<T, NT, KS, false, 2>(p, cshift, s);
+    }
+    if (st != PT_ERR_SHAPE) return st;
+  }
   int64_t blocks = (p.M + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if constexpr (std::is_same<T, float>::value) {
