@@ -197,9 +197,18 @@ class ARCodecDecoder(nn.Module):
 
                 if k > 1:
                     uniforms = uniforms.contiguous()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    step()
+                g = None
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        step()
+                except RuntimeError as e:                    # e.g. another capture in progress on this device: same step, launch by launch
+                    import warnings
+                    warnings.warn(f"ARCodecDecoder.generate: HIP graph capture failed ({e}); running the decode step launch by launch")
+                    g = None
                 for _ in range(n_eager, T):
-                    g.replay()
+                    if g is not None:
+                        g.replay()
+                    else:
+                        step()
         return codes
