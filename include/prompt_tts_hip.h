@@ -353,8 +353,9 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *     status word and the launch's XCD census).  Where the census finds every cluster on one XCD (a 256-CU device: read from the
  *     hardware per launch, never assumed) the exchange stays in that XCD's L2; otherwise it goes through memory (PT_LSTM_FORCE_
  *     REMOTE=1 forces that form).  Every workgroup of a launch must be resident at once; every wait is bounded;
- *   - persistent, f32-class (PT_F32, >= 64 CUs, exact_f32 == 0): clusters of 16 rows x 64 workgroups, bf16 x 3 products, the hi /
- *     lo weight fragments of a workgroup in registers and 16-byte granules, exchange through memory;
+ *   - persistent, f32-class (PT_F32, exact_f32 == 0): bf16 x 3 products, 16-byte granules {hi pair, lo pair, tag, tag}; the same
+ *     8-row x 32-workgroup clusters (eight waves per workgroup, hi / lo weight fragments in registers and LDS), XCD-local where the
+ *     census allows; PT_LSTM_F32_ROWS8=0: clusters of 16 rows x 64 workgroups exchanging through memory;
  *   - persistent, exact f32 (PT_F32, exact_f32 != 0): that kernel on v_mfma_f32_16x16x4_f32 with the f32 hidden values themselves
  *     in the granules (the Encodec ENCODER: 15.8 -> 9.3 ms per 32 x 900 frames against the per-step kernels);
  *   - per step (other H, small devices or inputs, PT_LSTM_PERSIST=0 / PT_LSTM_PERSIST_EXACT=0): T + 1 dependent launches (layer 0

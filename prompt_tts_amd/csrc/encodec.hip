@@ -1023,6 +1023,218 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
   }
 }
 
+// ---- persistent 2-layer LSTM, f32-class, 8-row clusters on one XCD ------------------------------------------------------------
+// lstm2_persist8_kernel's plan for the f32-class arithmetic of lstm2_persist3_kernel (bf16 x 3 products, 16-byte granules
+// {hi pair, lo pair, tag, tag}): clusters of 8 rows x 32 workgroups, cluster = XCD where the census allows it.  A workgroup's 16
+// units x 4 gates x 1536 inputs are 384 KiB of hi + lo weights: EIGHT waves split the reduction (two 32-unit k-blocks of h0 and
+// of h1 each), a wave keeps 40 of its 48 B fragments in registers (160 per lane) and the lo fragments of the h1 part -- the
+// last-used eight -- in LDS (64 KiB per workgroup), which leaves room for the 256-register budget of two waves per SIMD.  A
+// workgroup pulls 64 KiB of granules per tick (whole 128-byte lines, one load per line, DPP exchange as in the bf16 kernel).
+struct LstmPersist8f {
+  int B, T, b_base, clusters;
+  const float* x; const float* xg0; const float* whh0; const float* wcat1; const float* bias1;
+  float* out_elu;
+  u32x4_t* gx;              // granules [2 parity][2 layer][clusters * 8 rows][256 unit pairs]; zeroed by the launch function
+  unsigned* err; int spin_limit; int fault_slice;
+  unsigned* census; int force_remote;
+};
+constexpr int L8F_WAVES = 8;
+
+template <int AUX>
+__device__ __forceinline__ void l8f_load(u32x4_t (&v0)[4], u32x4_t (&v1)[4], __amdgpu_buffer_rsrc_t grs, int voff0, int voff1, bool need1) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v0[i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * i, 0, AUX);
+  if (need1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v1[i] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * i, 0, AUX);
+  }
+}
+
+__global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(const LstmPersist8f p) {
+  __shared__ float red[L8F_WAVES * 8 * 4 * 32];                       // [wave][layer * 4 + gate][r][lane & 31]: 32 KiB
+  __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * 2 * 4 * 1024];   // lo fragments of the h1 part: [wave][k][gate][lane] x 16 B
+  __shared__ int abort_word;
+  __shared__ int cfg[3];
+  int* abort_flag = &abort_word;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int rows = p.clusters * L8_ROWS;
+  if (tid == 0) {                                            // census: see lstm2_persist8_kernel
+    const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 15u;
+    const unsigned ticket = __hip_atomic_fetch_add(p.census + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p.census + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spin = 0;
+    bool lost = false;
+    while (__hip_atomic_load(p.census + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x) {
+      if (++spin > p.spin_limit) { lost = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    bool local = !lost && !p.force_remote && gridDim.x == 8 * L8_SLICES && xcc < 8u;
+    for (int x = 0; x < 8 && local; ++x)
+      local = __hip_atomic_load(p.census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)L8_SLICES;
+    if (lost) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cfg[0] = lost ? -1 : (local ? (int)xcc : (int)(blockIdx.x / L8_SLICES));
+    cfg[1] = local ? (int)ticket : (int)(blockIdx.x % L8_SLICES);
+    cfg[2] = local;
+    *abort_flag = 0;
+  }
+  __syncthreads();
+  const int c = __builtin_amdgcn_readfirstlane(cfg[0]), u = __builtin_amdgcn_readfirstlane(cfg[1]);
+  const bool local = __builtin_amdgcn_readfirstlane(cfg[2]) != 0;
+  if (c < 0 || c >= p.clusters) return;
+
+  // ---- weights of this wave's k-blocks kb = 2 wave + k: column tile tl = gate, column li = unit 16 u + li; slot j of lane (li, g)
+  //      = hidden unit 32 kb + 8 (j >> 1) + 2 g + (j & 1) (split_bf16x8's order = the order the granule loads deliver) ----
+  Frag<bf16_t> w0h[2][4], w0l[2][4], w1ah[2][4], w1al[2][4], w1bh[2][4];
+  char* wl = wlds + wave * 8192;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+      const int64_t grow = (int64_t)tl * LP_H + L8_UNITS * u + li;
+      const int k0 = 32 * (2 * wave + k) + 2 * g;
+      split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
+      split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
+      Frag<bf16_t> lo;
+      split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
+      *reinterpret_cast<bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16) = lo.v;
+    }
+  // ---- gate-math role (threads 0 .. 255): (layer, batch row, unit) ----
+  const bool gater = tid < 256;
+  const int layer = (tid >> 7) & 1, b = (tid >> 4) & 7, jj = tid & 15;
+  const int bglob = p.b_base + L8_ROWS * c + b;
+  const bool bvalid = gater && bglob < p.B;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gater && layer == 1) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + L8_UNITS * u + jj];
+  }
+  float cstate = 0.f;
+  const int gbytes = 2 * 2 * rows * 256 * 16;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, gbytes, 0x00020000);
+  __syncthreads();
+
+  for (int s = 0; s <= p.T; ++s) {
+    const bool l0 = s < p.T, l1 = s >= 1;
+    float xg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gater && layer == 0 && l0 && bvalid) {
+      const float* xp = p.xg0 + ((int64_t)bglob * p.T + s) * (4 * LP_H) + L8_UNITS * u + jj;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) xg[gi] = xp[gi * LP_H];
+    }
+    float xskip = 0.f;
+    const int64_t oi1 = ((int64_t)bglob * p.T + (s - 1)) * LP_H + L8_UNITS * u + jj;
+    if (gater && layer == 1 && l1 && bvalid) xskip = p.x[oi1];
+
+    f32x4_t acc[8];                                         // [layer * 4 + gate]: D[row = batch][col = unit]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (s >= 1) {
+      const int par = (s - 1) & 1;
+      const unsigned want = (unsigned)s;
+      // a k-block = 16 granules = two 128-byte lines of a row; lane (li, g) reads chunk g + 4 (li >> 3) of each line of row li & 7
+      const int row = L8_ROWS * c + (li & 7), chunk = g + 4 * (li >> 3);
+      const int voff0 = (((par * 2 + 0) * rows + row) * 256 + 32 * wave + chunk) * 16;
+      const int voff1 = (((par * 2 + 1) * rows + row) * 256 + 32 * wave + chunk) * 16;
+      const bool need1 = s >= 2;
+      u32x4_t v0[4], v1[4];                                 // [2 k + line]
+      int spin = 0;
+      bool aborted = false;
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v0[i] = (u32x4_t){0u, 0u, want, want}; v1[i] = (u32x4_t){0u, 0u, want, want}; }
+        if (local) l8f_load<2>(v0, v1, grs, voff0, voff1, need1);
+        else l8f_load<16>(v0, v1, grs, voff0, voff1, need1);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok &= (v0[i][2] == want) & (v0[i][3] == want) & (v1[i][2] == want) & (v1[i][3] == want);
+        if (__all(ok)) break;
+        if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          if (lane == 0) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abort_flag = 1; }
+          aborted = true;
+          break;
+        }
+      }
+      if (!aborted) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          // slots (0,1) own line 0, (2,3) lane li + 8's line 0, (4,5) own line 1, (6,7) lane li + 8's line 1; word 0 = hi pair, 1 = lo pair
+          Frag<bf16_t> a0h, a0l, a1h, a1l;
+          const u32x4_t h0 = {v0[2 * k][0], l8_from_upper(v0[2 * k][0]), v0[2 * k + 1][0], l8_from_upper(v0[2 * k + 1][0])};
+          const u32x4_t o0 = {v0[2 * k][1], l8_from_upper(v0[2 * k][1]), v0[2 * k + 1][1], l8_from_upper(v0[2 * k + 1][1])};
+          const u32x4_t h1 = {v1[2 * k][0], l8_from_upper(v1[2 * k][0]), v1[2 * k + 1][0], l8_from_upper(v1[2 * k + 1][0])};
+          const u32x4_t o1 = {v1[2 * k][1], l8_from_upper(v1[2 * k][1]), v1[2 * k + 1][1], l8_from_upper(v1[2 * k + 1][1])};
+          a0h.v = __builtin_bit_cast(bf16x8_t, h0); a0l.v = __builtin_bit_cast(bf16x8_t, o0);
+          a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0h, w0h[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a0h, w1ah[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0h, w0l[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a0h, w1al[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0l, w0h[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a0l, w1ah[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a1h, w1bh[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a1l, w1bh[k][tl]);
+#pragma unroll
+          for (int tl = 0; tl < 4; ++tl) {
+            Frag<bf16_t> wbl;
+            wbl.v = *reinterpret_cast<const bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16);
+            mma16(acc[4 + tl], a1h, wbl);
+          }
+        }
+      }
+    }
+    __syncthreads();                                        // the gate math of the previous tick has finished reading `red`
+    if (*abort_flag) return;
+    if (g < 2) {                                            // accumulator rows 4 g + r, g < 2, are the batch
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * 8 + i) * 4 + r) * 32 + (lane & 31)] = acc[i][r];
+    }
+    __syncthreads();
+    const bool active = gater && (layer == 0 ? l0 : l1);
+    float hn = 0.f;
+    if (active) {
+      float pre[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int tile = layer * 4 + gi, src_lane = jj + 16 * (b >> 2), r = b & 3;
+        float v = layer == 0 ? xg[gi] : bias[gi];
+#pragma unroll
+        for (int w = 0; w < L8F_WAVES; ++w) v += red[((w * 8 + tile) * 4 + r) * 32 + src_lane];
+        pre[gi] = v;
+      }
+      const float ig = lp_sigmoid(pre[0]), fg = lp_sigmoid(pre[1]), gg = lp_tanh(pre[2]), og = lp_sigmoid(pre[3]);
+      cstate = fg * cstate + ig * gg;
+      hn = og * lp_tanh(cstate);
+    }
+    if (gater && s < p.T) {
+      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
+      const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
+      const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
+      const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
+      if ((jj & 1) == 0) {
+        const unsigned tag = (unsigned)(s + 1) + (c * L8_SLICES + u == p.fault_slice ? 0x40000000u : 0u);
+        const u32x4_t gran = {hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
+        if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+      }
+    }
+    if (active && layer == 1 && bvalid) {
+      const float v = hn + xskip;
+      p.out_elu[oi1] = v < 0.f ? (expf(v) - 1.f) : v;
+    }
+  }
+}
+
 // ---- fused 24 kHz tail of the Encodec decoder (bf16) ------------------------------------------------------------------------
 // Last upsampling stage + its residual block + the final conv, one launch:
 //   xe [B][n][64] (ELU'd output of the previous stage, 12 kHz) -> transposed conv k4 s2 (64 -> 32, two taps x two phases)
@@ -1601,8 +1813,35 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
     }
     return PT_OK;
   }
-  // f32 (the reference's precision): the same persistent plan with bf16 x 3 products and register-resident hi / lo weights
+  // f32-class (the decoder at the reference's precision): 8-row clusters on one XCD each (lstm2_persist8f_kernel) ...
   static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
+  const int rows8f = pt_env_int("PT_LSTM_F32_ROWS8", 1);              // read per call: tests compare the forms
+  const int64_t ws_need8f = 512 + 2ll * 2 * 64 * 256 * 16;
+  if (persist && persist3 && rows8f && !d->exact_f32 && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
+    const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
+    const int rows_per_launch = L8_ROWS * max_clusters8;
+    for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
+      LstmPersist8f q;
+      q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
+      const int64_t nb = d->B - b0 < rows_per_launch ? d->B - b0 : rows_per_launch;
+      q.clusters = (int)((nb + L8_ROWS - 1) / L8_ROWS);
+      q.x = (const float*)d->x; q.xg0 = (const float*)d->xg0; q.whh0 = (const float*)d->whh0; q.wcat1 = (const float*)d->wcat1;
+      q.bias1 = d->bias1; q.out_elu = (float*)d->out_elu;
+      q.err = status;
+      q.gx = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(d->h0_seq) + 512);
+      q.census = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->h0_seq) + 256);
+      q.force_remote = pt_env_int("PT_LSTM_FORCE_REMOTE", 0);
+      q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
+      q.fault_slice = e_fault ? atoi(e_fault) : -1;
+      const bool first = b0 == 0;
+      char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
+      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
+      hipLaunchKernelGGL(lstm2_persist8f_kernel, dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
+      PT_LAUNCH_CHECK();
+    }
+    return PT_OK;
+  }
+  // ... else 16-row clusters x 64 workgroups, exchange through memory; exact f32 (the encoder) always takes that form
   const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
   // exact_f32: the same kernel on the exact f32 MFMA (PT_LSTM_PERSIST_EXACT=0: the per-step kernels)
   const int persist_exact = pt_env_int("PT_LSTM_PERSIST_EXACT", 1);      // read per call: tests compare the two forms

@@ -395,13 +395,18 @@ def test_persistent_lstm_timeout_in_a_later_launch_of_the_call_is_sticky(dev, mo
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(20, 150), (70, 40), (5, 300)])
-def test_persistent_f32_lstm_decoder_vs_oracle(dev, B, T):
-    """f32 decode at sizes that take the PERSISTENT f32-class LSTM (bf16 x 3 products, hi / lo weight fragments in registers,
-    16-byte data-tagged granules): 2, 4 + 1 (two launches, ragged last cluster) and 1 cluster(s), against the CPU oracle at the
-    north_star bound for floating point (1e-3 of the waveform peak; the exact-f32 per-step kernels measure ~1e-6)."""
+@pytest.mark.parametrize("B,T,form", [(20, 150, "local"), (70, 40, "local"), (5, 300, "local"), (20, 150, "remote"), (70, 40, "rows16")])
+def test_persistent_f32_lstm_decoder_vs_oracle(dev, B, T, form, monkeypatch):
+    """f32 decode at sizes that take the PERSISTENT f32-class LSTM (bf16 x 3 products, hi / lo weight fragments in registers / LDS,
+    16-byte data-tagged granules): 3, 8 + 1 (two launches, ragged last cluster) and 1 cluster(s) of 8 rows on one XCD each
+    ("local"), the same kernel exchanging through memory ("remote"), and the 16-row x 64-workgroup kernel ("rows16"), against the
+    CPU oracle at the north_star bound for floating point (1e-3 of the waveform peak; the exact-f32 per-step kernels: ~1e-6)."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
+    if form == "remote":
+        monkeypatch.setenv("PT_LSTM_FORCE_REMOTE", "1")
+    if form == "rows16":
+        monkeypatch.setenv("PT_LSTM_F32_ROWS8", "0")
     W = oe.random_weights(5)
     codes = torch.randint(0, 1024, (B, 8, T), generator=torch.Generator().manual_seed(B + T))
     got = EncodecDecoder(W, device=dev, dtype=torch.float32).decode(codes.to(dev)).cpu()
