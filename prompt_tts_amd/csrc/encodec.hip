@@ -1050,9 +1050,12 @@ __device__ __forceinline__ void l8f_load(u32x4_t (&v0)[4], u32x4_t (&v1)[4], __a
   }
 }
 
+// EXACT: f32 weights, f32 hidden values in the granules, v_mfma_f32_16x16x4_f32 (the encoder); its h1-part weights are 128 KiB as
+// f32: two of the eight (k-block, gate) pieces stay in registers, six live in LDS (96 KiB)
+template <bool EXACT>
 __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(const LstmPersist8f p) {
   __shared__ float red[L8F_WAVES * 8 * 4 * 32];                       // [wave][layer * 4 + gate][r][lane & 31]: 32 KiB
-  __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * 2 * 4 * 1024];   // lo fragments of the h1 part: [wave][k][gate][lane] x 16 B
+  __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * (EXACT ? 6 * 2048 : 8 * 1024)];   // h1-part weights: lo fragments [wave][k][gate][lane] x 16 B / EXACT: six f32 pieces x 32 B
   __shared__ int abort_word;
   __shared__ int cfg[3];
   int* abort_flag = &abort_word;
@@ -1085,18 +1088,38 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
   // ---- weights of this wave's k-blocks kb = 2 wave + k: column tile tl = gate, column li = unit 16 u + li; slot j of lane (li, g)
   //      = hidden unit 32 kb + 8 (j >> 1) + 2 g + (j & 1) (split_bf16x8's order = the order the granule loads deliver) ----
   Frag<bf16_t> w0h[2][4], w0l[2][4], w1ah[2][4], w1al[2][4], w1bh[2][4];
-  char* wl = wlds + wave * 8192;
+  float x0[2][4][8], x1a[2][4][8], x1br[2][8];               // EXACT: f32 weights; x1br = the h1 part of (k = 0, gates 0, 1)
+  char* wl = wlds + wave * (EXACT ? 6 * 2048 : 8192);
 #pragma unroll
   for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
       const int64_t grow = (int64_t)tl * LP_H + L8_UNITS * u + li;
       const int k0 = 32 * (2 * wave + k) + 2 * g;
-      split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
-      split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
-      Frag<bf16_t> lo;
-      split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
-      *reinterpret_cast<bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16) = lo.v;
+      if constexpr (EXACT) {
+        float t1b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = 8 * (j >> 1) + (j & 1);
+          x0[k][tl][j] = p.whh0[grow * LP_H + k0 + o];
+          x1a[k][tl][j] = p.wcat1[grow * 2 * LP_H + k0 + o];
+          t1b[j] = p.wcat1[grow * 2 * LP_H + LP_H + k0 + o];
+        }
+        if (k == 0 && tl < 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x1br[tl][j] = t1b[j];
+        } else {
+          float* dst = reinterpret_cast<float*>(wl + ((k * 4 + tl - 2) * 64 + lane) * 32);
+          *reinterpret_cast<f32x4_t*>(dst) = (f32x4_t){t1b[0], t1b[1], t1b[2], t1b[3]};
+          *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){t1b[4], t1b[5], t1b[6], t1b[7]};
+        }
+      } else {
+        split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
+        split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
+        Frag<bf16_t> lo;
+        split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
+        *reinterpret_cast<bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16) = lo.v;
+      }
     }
   // ---- gate-math role (threads 0 .. 255): (layer, batch row, unit) ----
   const bool gater = tid < 256;
@@ -1154,6 +1177,29 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
           break;
         }
       }
+      if constexpr (EXACT) {
+        if (!aborted) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              // slot j: granule j >> 1 of the lane's four (own line 0, lane li + 8's line 0, own line 1, lane li + 8's line 1), word j & 1
+              const unsigned r0 = v0[2 * k + (j >> 2)][j & 1], r1 = v1[2 * k + (j >> 2)][j & 1];
+              const float a0 = __uint_as_float(((j >> 1) & 1) ? l8_from_upper(r0) : r0), a1 = __uint_as_float(((j >> 1) & 1) ? l8_from_upper(r1) : r1);
+#pragma unroll
+              for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][tl][j], acc[tl], 0, 0, 0);
+#pragma unroll
+              for (int tl = 0; tl < 4; ++tl) acc[4 + tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x1a[k][tl][j], acc[4 + tl], 0, 0, 0);
+#pragma unroll
+              for (int tl = 0; tl < 4; ++tl) {
+                float w;
+                if (k == 0 && tl < 2) w = x1br[tl][j];
+                else w = reinterpret_cast<const float*>(wl + ((k * 4 + tl - 2) * 64 + lane) * 32)[j];
+                acc[4 + tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w, acc[4 + tl], 0, 0, 0);
+              }
+            }
+        }
+      } else
       if (!aborted) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -1211,18 +1257,25 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
         for (int w = 0; w < L8F_WAVES; ++w) v += red[((w * 8 + tile) * 4 + r) * 32 + src_lane];
         pre[gi] = v;
       }
-      const float ig = lp_sigmoid(pre[0]), fg = lp_sigmoid(pre[1]), gg = lp_tanh(pre[2]), og = lp_sigmoid(pre[3]);
-      cstate = fg * cstate + ig * gg;
-      hn = og * lp_tanh(cstate);
+      if constexpr (EXACT) {
+        const float ig = 1.f / (1.f + expf(-pre[0])), fg = 1.f / (1.f + expf(-pre[1])), gg = tanhf(pre[2]), og = 1.f / (1.f + expf(-pre[3]));
+        cstate = fg * cstate + ig * gg;
+        hn = og * tanhf(cstate);
+      } else {
+        const float ig = lp_sigmoid(pre[0]), fg = lp_sigmoid(pre[1]), gg = lp_tanh(pre[2]), og = lp_sigmoid(pre[3]);
+        cstate = fg * cstate + ig * gg;
+        hn = og * lp_tanh(cstate);
+      }
     }
     if (gater && s < p.T) {
       // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
       const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
       const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
       const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
+      const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
       if ((jj & 1) == 0) {
         const unsigned tag = (unsigned)(s + 1) + (c * L8_SLICES + u == p.fault_slice ? 0x40000000u : 0u);
-        const u32x4_t gran = {hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), hn_o, tag, tag} : (u32x4_t){hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
         u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
         if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
@@ -1817,7 +1870,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
   const int rows8f = pt_env_int("PT_LSTM_F32_ROWS8", 1);              // read per call: tests compare the forms
   const int64_t ws_need8f = 512 + 2ll * 2 * 64 * 256 * 16;
-  if (persist && persist3 && rows8f && !d->exact_f32 && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
+  if (persist && (d->exact_f32 ? pt_env_int("PT_LSTM_PERSIST_EXACT", 1) : persist3) && rows8f && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = L8_ROWS * max_clusters8;
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
@@ -1836,12 +1889,13 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
-      hipLaunchKernelGGL(lstm2_persist8f_kernel, dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
+      if (d->exact_f32) hipLaunchKernelGGL((lstm2_persist8f_kernel<true>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
+      else hipLaunchKernelGGL((lstm2_persist8f_kernel<false>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
       PT_LAUNCH_CHECK();
     }
     return PT_OK;
   }
-  // ... else 16-row clusters x 64 workgroups, exchange through memory; exact f32 (the encoder) always takes that form
+  // ... else 16-row clusters x 64 workgroups, exchange through memory
   const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
   // exact_f32: the same kernel on the exact f32 MFMA (PT_LSTM_PERSIST_EXACT=0: the per-step kernels)
   const int persist_exact = pt_env_int("PT_LSTM_PERSIST_EXACT", 1);      // read per call: tests compare the two forms

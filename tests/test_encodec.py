@@ -308,8 +308,8 @@ def test_hip_encoder_vs_oracle(dev, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(20, 60), (70, 24)])
-def test_exact_f32_persistent_lstm_of_the_encoder(dev, B, T, monkeypatch):
+@pytest.mark.parametrize("B,T,rows16", [(20, 60, 0), (70, 24, 0), (20, 60, 1)])
+def test_exact_f32_persistent_lstm_of_the_encoder(dev, B, T, rows16, monkeypatch):
     """The encoder's LSTM at sizes that take the PERSISTENT exact-f32 form (v_mfma_f32_16x16x4_f32, f32 hidden values in the
     granules; 2 clusters; 4 + 1 clusters in two launches): embeddings against the per-step kernels (same arithmetic, another
     summation order: 1e-5 of the peak) and against the CPU oracle (1e-3), codes against the oracle's."""
@@ -318,6 +318,8 @@ def test_exact_f32_persistent_lstm_of_the_encoder(dev, B, T, monkeypatch):
     W = oe.random_encoder_weights(6)
     wav = torch.randn(B, 1, 320 * T, generator=torch.Generator().manual_seed(B + T)) * 0.5
     enc = EncodecEncoder(W, device=dev, dtype=torch.float32)
+    if rows16:                                                            # the 16-row x 64-workgroup kernel instead of 8 rows per XCD
+        monkeypatch.setenv("PT_LSTM_F32_ROWS8", "0")
     emb, b, t = enc.embeddings(wav.to(dev))
     monkeypatch.setenv("PT_LSTM_PERSIST_EXACT", "0")
     emb_step, _, _ = enc.embeddings(wav.to(dev))
