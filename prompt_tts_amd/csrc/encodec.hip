@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void l8f_load(u32x4_t (&v0)[4], u32x4_t (&v1)[4], __a
 template <bool EXACT>
 __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(const LstmPersist8f p) {
   __shared__ float red[L8F_WAVES * 8 * 4 * 32];                       // [wave][layer * 4 + gate][r][lane & 31]: 32 KiB
-  __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * (EXACT ? 6 * 2048 : 8 * 1024)];   // h1-part weights: lo fragments [wave][k][gate][lane] x 16 B / EXACT: six f32 pieces x 32 B
+  __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * (EXACT ? 6 * 2048 : 12 * 1024)];   // h1-part weights: lo fragments [wave][k][gate][lane] x 16 B / EXACT: six f32 pieces x 32 B
   __shared__ int abort_word;
   __shared__ int cfg[3];
   int* abort_flag = &abort_word;
@@ -1087,9 +1087,9 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
 
   // ---- weights of this wave's k-blocks kb = 2 wave + k: column tile tl = gate, column li = unit 16 u + li; slot j of lane (li, g)
   //      = hidden unit 32 kb + 8 (j >> 1) + 2 g + (j & 1) (split_bf16x8's order = the order the granule loads deliver) ----
-  Frag<bf16_t> w0h[2][4], w0l[2][4], w1ah[2][4], w1al[2][4], w1bh[2][4];
+  Frag<bf16_t> w0h[2][4], w0l[2][4], w1ah[2][4], w1al[4], w1bh[2][4];        // w1al: k-block 0 only (k-block 1 in LDS)
   float x0[2][4][8], x1a[2][4][8], x1br[2][8];               // EXACT: f32 weights; x1br = the h1 part of (k = 0, gates 0, 1)
-  char* wl = wlds + wave * (EXACT ? 6 * 2048 : 8192);
+  char* wl = wlds + wave * (EXACT ? 6 * 2048 : 12288);     // f32-class: pieces 0..7 = w1bl[k][tl], 8..11 = w1al[1][tl]
 #pragma unroll
   for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -1115,8 +1115,9 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
         }
       } else {
         split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
-        split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], w1al[k][tl]);
         Frag<bf16_t> lo;
+        split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], lo);
+        if (k == 0) w1al[tl] = lo; else *reinterpret_cast<bf16x8_t*>(wl + ((8 + tl) * 64 + lane) * 16) = lo.v;
         split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
         *reinterpret_cast<bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16) = lo.v;
       }
@@ -1218,7 +1219,10 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
 #pragma unroll
           for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0h, w0l[k][tl]);
 #pragma unroll
-          for (int tl = 0; tl < 4; ++tl) mma16(acc[4 + tl], a0h, w1al[k][tl]);
+          for (int tl = 0; tl < 4; ++tl) {
+            if (k == 0) mma16(acc[4 + tl], a0h, w1al[tl]);
+            else { Frag<bf16_t> wal; wal.v = *reinterpret_cast<const bf16x8_t*>(wl + ((8 + tl) * 64 + lane) * 16); mma16(acc[4 + tl], a0h, wal); }
+          }
 #pragma unroll
           for (int tl = 0; tl < 4; ++tl) mma16(acc[tl], a0l, w0h[k][tl]);
 #pragma unroll
