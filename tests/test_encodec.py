@@ -429,3 +429,20 @@ def test_persistent_f32_lstm_timeout_raises(dev, monkeypatch):
     with pytest.raises(RuntimeError, match="timed out"):
         dec.decode(codes)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n", [(torch.bfloat16, 12), (torch.float32, 5)])
+def test_decode_is_bit_identical_from_launch_to_launch(dev, dtype, n):
+    """configs[3] size (64 x 1024 frames, 1024 recurrent ticks, 8 XCD-local clusters): the census hands out the unit slices of a
+    cluster in arrival order, so WHICH workgroup computes which hidden units changes from launch to launch -- the arithmetic
+    never does.  Every decode must return the first one's waveform bit for bit (a stale or torn hand-off would not), and no
+    status word may fire (decode() raises)."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    dec = EncodecDecoder(oe.random_weights(6), device=dev, dtype=dtype)
+    codes = torch.randint(0, 1024, (64, 8, 1024), generator=torch.Generator().manual_seed(11)).to(dev)
+    ref = dec.decode(codes).clone()
+    assert torch.isfinite(ref).all()
+    for _ in range(n):
+        assert torch.equal(dec.decode(codes), ref)
