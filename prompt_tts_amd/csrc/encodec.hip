@@ -1027,8 +1027,9 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
 // lstm2_persist8_kernel's plan for the f32-class arithmetic of lstm2_persist3_kernel (bf16 x 3 products, 16-byte granules
 // {hi pair, lo pair, tag, tag}): clusters of 8 rows x 32 workgroups, cluster = XCD where the census allows it.  A workgroup's 16
 // units x 4 gates x 1536 inputs are 384 KiB of hi + lo weights: EIGHT waves split the reduction (two 32-unit k-blocks of h0 and
-// of h1 each), a wave keeps 40 of its 48 B fragments in registers (160 per lane) and the lo fragments of the h1 part -- the
-// last-used eight -- in LDS (64 KiB per workgroup), which leaves room for the 256-register budget of two waves per SIMD.  A
+// of h1 each), a wave keeps 36 of its 48 B fragments in registers (144 per lane) and twelve lo fragments -- the h1 part's eight and
+// the second k-block's four of layer 1's h0 part -- in LDS (96 KiB per workgroup): 248 registers per lane, no spills, at the two
+// waves per SIMD an eight-wave workgroup needs.  A
 // workgroup pulls 64 KiB of granules per tick (whole 128-byte lines, one load per line, DPP exchange as in the bf16 kernel).
 struct LstmPersist8f {
   int B, T, b_base, clusters;
