@@ -373,7 +373,7 @@ template <typename T, int NT, int KS, bool X3, int RT> int launch_rowconv_staged
 
 template <typename T, int NT, int KS> int launch_rowconv(const RowConvParams& p, hipStream_t s) {
   // inputs read more than once (taps > stride), whole power-of-two rows, enough rows per item: the LDS-staged kernel
-  static const int staged_on = pt_env_int("PT_ROWCONV_STAGED", 1);
+  const int staged_on = pt_env_int("PT_ROWCONV_STAGED", 1);          // read per call: tests compare the two kernels
   const int stride = p.rowmap == PT_MAP_STRIDED_REFLECT ? p.stride : 1;
   if (staged_on && (!p.x2 || p.cin2 == 0) && p.taps > stride && (p.cin & (p.cin - 1)) == 0 && p.cin >= 8 && p.cin <= 64 && p.n_rows >= 256 && p.M >= 4096) {
     int cshift = 0;

@@ -446,3 +446,52 @@ def test_decode_is_bit_identical_from_launch_to_launch(dev, dtype, n):
     assert torch.isfinite(ref).all()
     for _ in range(n):
         assert torch.equal(dec.decode(codes), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,x3", [(torch.float32, 1), (torch.float32, 0), (torch.bfloat16, 0)])
+@pytest.mark.parametrize("cin,taps,N,rowmap,stride", [(32, 7, 1, "causal", 1), (64, 3, 32, "causal", 1), (64, 2, 64, "back", 1),
+                                                      (32, 4, 64, "strided", 2), (16, 3, 16, "causal", 1)])
+def test_rowconv_staged_through_lds_equals_the_global_memory_kernel(dev, dtype, x3, cin, taps, N, rowmap, stride, monkeypatch):
+    """pt_rowconv with its input rows staged through LDS (interior blocks; input ELU and hi / lo split applied while staging)
+    against the kernel that fetches every tap from global memory (PT_ROWCONV_STAGED=0): same products in the same order -> the
+    same bits in the interior; three items of 2 024 rows so that blocks at item starts / ends (reflect, zero padding, two items in one block)
+    take the edge path inside the staged kernel."""
+    import ctypes as C
+    from prompt_tts_amd import _lib as L, ops
+    from prompt_tts_amd._lib import lib
+    g = torch.Generator().manual_seed(cin * 100 + taps)
+    B, n_out = 3, 2000 + 24                     # M = 6 072 rows: above the staged kernel's 4 096-row threshold
+    n_in = n_out * stride
+    K = taps * cin
+    ldw = (K + 31) // 32 * 32
+    x = torch.randn(B * n_in, cin, generator=g).to(dev, dtype)
+    w = torch.zeros(N, ldw); w[:, :K] = torch.randn(N, K, generator=g) * K ** -0.5
+    w = w.to(dev, dtype)
+    bias = torch.randn(N, generator=g).to(dev)
+    rm = {"causal": L.PT_MAP_CAUSAL_REFLECT, "back": L.PT_MAP_BACK, "strided": L.PT_MAP_STRIDED_REFLECT}[rowmap]
+
+    def run():
+        y = torch.full((B * n_out, max(N, 4)), float("nan"), device=dev, dtype=dtype)
+        d = L.pt_rowconv_desc()
+        d.B, d.n_rows = B, n_out
+        d.x, d.ldx, d.cin, d.taps, d.rowmap, d.elu_x, d.stride = x.data_ptr(), x.stride(0), cin, taps, rm, 1, stride
+        d.w, d.ldw, d.bias, d.N, d.act = w.data_ptr(), w.stride(0), bias.data_ptr(), N, 1
+        d.y, d.ldy, d.y_f32, d.f32_x3 = y.data_ptr(), y.stride(0), 0, x3
+        ops.check(lib.pt_rowconv(C.byref(d), ops._DT[dtype], ops._stream()), "pt_rowconv")
+        return y[:, :N].clone()
+    staged = run()
+    monkeypatch.setenv("PT_ROWCONV_STAGED", "0")
+    plain = run()
+    assert torch.isfinite(staged).all()
+    s3, p3 = staged.view(B, n_out, N), plain.view(B, n_out, N)
+    assert torch.equal(s3[:, 128:n_out - 128], p3[:, 128:n_out - 128])          # blocks staged through LDS: the same bits
+    # blocks at an item edge add their k-steps in another order (last-bit differences)
+    assert float((s3.float() - p3.float()).abs().max()) <= 4e-6 * float(p3.float().abs().max())
+    # and against plain torch on a few rows of the middle item (f32 exact only)
+    if dtype == torch.float32 and not x3 and rowmap == "causal":
+        xe = torch.nn.functional.elu(x.float().cpu().view(B, n_in, cin))[1]
+        t = 500
+        ref = sum(xe[t + tap - (taps - 1)] @ w.float().cpu()[:, tap * cin:(tap + 1) * cin].T for tap in range(taps)) + bias.cpu()
+        ref = torch.nn.functional.elu(ref)
+        assert float((staged[n_out + t].float().cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
