@@ -38,3 +38,30 @@ def test_greedy_and_topk_indices_bit_exact(dev, dtype, V, k):
     # ties: greedy must return the FIRST maximum, as torch.argmax
     flat = torch.zeros(8, V, dtype=dtype); flat[:, 5] = 1; flat[:, 9] = 1
     assert torch.equal(ops.sample_topk(flat.to(dev), 1).cpu(), torch.full((8,), 5))
+
+
+def test_packed_key_topk_edge_cases(dev):
+    """The bf16 packed-key kernel (V <= 1024): a row length that is not a multiple of 16 (the last lanes take the element-wise load
+    path), -0.0 against +0.0 (equal: the lower column wins), -inf entries, a row stride that is not a multiple of 8, and k = V."""
+    from oracle import collate as oc
+    from prompt_tts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    # argmax with signed zeros and -inf: first maximum wins
+    z = torch.full((4, 1000), float("-inf"), dtype=torch.bfloat16)
+    z[0, 7] = -0.0; z[0, 3] = 0.0; z[0, 900] = 0.0                      # max 0 at columns 3, 7 (-0), 900 -> 3
+    z[1, 999] = -5.0                                                     # a single finite entry in the very last column
+    z[2, :] = -1.0; z[2, 512] = -0.5
+    z[3, 17] = 3.0; z[3, 16] = 3.0
+    assert ops.sample_topk(z.to(dev), 1).cpu().tolist() == [3, 999, 512, 16]
+    # top-k with distinct values on V = 1000 and on a strided view (ld = 1003)
+    base = (torch.arange(1000, dtype=torch.int16) + 0x3C00).view(torch.bfloat16)    # 1000 consecutive (distinct, finite) bf16 values
+    base = torch.where(torch.arange(1000) % 3 == 0, -base, base)                    # mixed signs, still distinct
+    rows = torch.stack([base[torch.randperm(1000, generator=g)] for _ in range(33)])
+    assert rows.dtype == torch.bfloat16 and all(len(torch.unique(r.float())) == 1000 for r in rows)
+    u = torch.rand(33, generator=g)
+    for k in (2, 31, 64):
+        want = oc.sample_topk(rows.float(), k, u, temperature=1.3)
+        assert torch.equal(ops.sample_topk(rows.to(dev), k, u.to(dev), temperature=1.3).cpu(), want)
+    wide = torch.zeros(33, 1003, dtype=torch.bfloat16); wide[:, :1000] = rows
+    view = wide.to(dev)[:, :1000]                                                   # ld = 1003: element-wise loads
+    assert torch.equal(ops.sample_topk(view, 31, u.to(dev), temperature=1.3).cpu(), oc.sample_topk(rows.float(), 31, u, temperature=1.3))
