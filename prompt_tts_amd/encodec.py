@@ -180,7 +180,9 @@ class EncodecDecoder:
     # -- decode -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, codes):
-        """codes (B, n_q, T) int64 in [0,1023] -> wav (B, 1, 320*T) f32."""
+        """codes (B, n_q, T) int64 in [0,1023] -> wav (B, 1, 320*T) f32.
+        One call at a time per decoder AND per GPU: the persistent LSTM wants every CU of the device for the length of its launch
+        (two of them in flight on two streams alternate at a crawl) and the decoder owns one status word."""
         wav, lstm_status = self._decode(codes)
         lstm_status.check()              # never hand out a waveform computed from a timed-out recurrence
         return wav
