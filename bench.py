@@ -276,6 +276,7 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.bfloat16, cpu=Tru
     out = {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
            "ms_per_batch": ms, "prompts": prompts, "frames": T, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
            "lstm_ms": lstm_ms, "lstm_steps_per_s": 2 * T / (lstm_ms * 1e-3) if lstm_ms else None,
+           "lstm_us_per_tick": lstm_ms * 1e3 / (T + 1) if lstm_ms else None,
            "achieved_tflops": flops / (ms * 1e-3) / 1e12,
            # the decode is compute / latency bound (19.9 M MAC per frame against 1.3 KB of algorithmic I/O per frame): priced
            # against the dense bf16 MFMA peak; the launch-boundary HBM view of the conv stack stays as `hbm_view`
