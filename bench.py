@@ -356,6 +356,10 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the Encodec decode leg (audio-s/s)")
     ap.add_argument("--kernel-timing", action="store_true", help="per-symbol HIP-event timing of one extra step")
     ap.add_argument("--only-decode", action="store_true", help="only the Encodec decode leg (configs[3]); for the decode PMC passes")
+    ap.add_argument("--no-replay", action="store_true",
+                    help="skip the instrumented extra step and the isolated replays (and the decode / encode / sampling legs): the "
+                         "process then launches nothing but warm-up + timed steps, so a `rocprofv3 --kernel-trace --stats` summary "
+                         "of this command holds IN-STEP averages only (tools/profile_round.sh)")
     args = ap.parse_args()
 
     if args.only_decode:
@@ -396,6 +400,8 @@ def main():
     # (AR inference stays single-GPU), and measured behind the training leg -- 30 GB of cached allocations, three extra streams --
     # the same decode loop read 16.5 instead of 11.5 ms per batch although every kernel took the same time
     pre = {}
+    if args.no_replay:
+        args.no_decode = True
     if rank == 0 and world == 1 and not args.no_decode:
         note("decode leg (configs[3]: 64 prompts x 1024 frames)")
         pre["decode"] = decode_bench(dev, cpu=not args.no_cpu_baseline)
@@ -478,7 +484,7 @@ def main():
             out["allreduce_ms"] = float(tt[0]); out["allreduce_exposed_ms"] = float(tt[1])
             out["allreduce_overlap_pct"] = 100.0 * (1.0 - float(tt[1]) / float(tt[0])) if float(tt[0]) > 0 else 0.0
             out["allreduce_buckets"] = tm["buckets"]; out["allreduce_bytes_per_step"] = tm["bytes"]
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_replay:
         # per-class device times of ONE extra step (HIP events around every C-ABI call, recorded on the stream the call is
         # launched on: the weight gradients run on the side stream); the dominant class's average is what the committed
         # profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command) must agree with.

@@ -11,9 +11,15 @@
  *     weight shadows: PT_F32 (parity mode, exact-f32 MFMA) or PT_BF16 (bf16 MFMA, f32 accumulate);
  *   - statistics, biases, LSE, losses, master weights and ALL weight gradients are f32;
  *   - return value 0 = launched; <0 = refused before any launch (see pt_status); never throws.
- *   - re-entrant and thread-safe.  Process-wide state is limited to: diagnostic switches read from the environment once
- *     (thread-safe function-local statics; the defaults are the product), and the per-THREAD word behind
- *     pt_last_hip_error().  Nothing else outlives a call.
+ *   - thread-safe: any entry point may be called from several host threads at once.  Process-wide state is limited to
+ *     diagnostic switches read from the environment (the defaults are the product), the per-THREAD word behind
+ *     pt_last_hip_error(), and ONE mutex-guarded event per device that orders the persistent LSTM launches (below).
+ *   - concurrency on the DEVICE: every entry point may run beside any other on another stream, as long as the two calls
+ *     share no output / scratch buffer -- with ONE exception, pt_lstm2_forward in its persistent forms: such a launch needs
+ *     all of its workgroups resident at once (one per CU), so two of them must not overlap on one device.  The library
+ *     enforces that itself: a call's persistent launches wait on the device (hipStreamWaitEvent) for the previous call's,
+ *     whatever stream that was on (see pt_lstm2_forward).  Other kernels that hold CUs for long (another library's
+ *     persistent kernels, a CU-masked stream) can still starve it: every wait inside is bounded and ends in the status word.
  */
 #ifndef PROMPT_TTS_HIP_H
 #define PROMPT_TTS_HIP_H
@@ -347,19 +353,23 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *   layer 1 uses wcat1 [4H][2H] = [W_ih1 | W_hh1] and bias1 [4H] = b_ih1 + b_hh1
  *   out_elu[(b,t)][:] = ELU(h1_t + x[(b,t)][:])
  * h0_seq, h1_seq [B*T][H] and c0, c1 [B][H] (f32) are caller-provided scratch.  Two forms, chosen by the library:
- *   - persistent (PT_BF16, H = 512, B*T*H*2 >= 256 KiB + 512, a device with >= 32 CUs): ONE launch per 8 * min(8, CUs / 32)
+ *   - persistent (PT_BF16, H = 512, h0_seq of B*T*H*2 >= 512 KiB + 512 bytes -- PT_F32: B*T*H*4 >= 1 MiB + 512 -- a device with >= 32 CUs): ONE launch per 8 * min(8, CUs / 32)
  *     batch rows runs all T steps with the recurrent weights resident in registers; clusters of 8 rows x 32 workgroups (one per
  *     CU) exchange the new hidden vectors every step through data-tagged 8-byte granules in h0_seq (its first 512 bytes hold the
  *     status word and the launch's XCD census).  Where the census finds every cluster on one XCD (a 256-CU device: read from the
  *     hardware per launch, never assumed) the exchange stays in that XCD's L2; otherwise it goes through memory (PT_LSTM_FORCE_
  *     REMOTE=1 forces that form).  Every workgroup of a launch must be resident at once; every wait is bounded;
- *   - persistent, f32-class (PT_F32, exact_f32 == 0): bf16 x 3 products, 16-byte granules {hi pair, lo pair, tag, tag}; the same
+ *   - persistent, f32-class (PT_F32, exact_f32 == 0): bf16 x 3 products, 16-byte granules {hi pair, tag, lo pair, tag} (one tag
+ *     per 8-byte half: a torn 16-byte access cannot pass the check); the same
  *     8-row x 32-workgroup clusters (eight waves per workgroup, hi / lo weight fragments in registers and LDS), XCD-local where the
  *     census allows; PT_LSTM_F32_ROWS8=0: clusters of 16 rows x 64 workgroups exchanging through memory;
  *   - persistent, exact f32 (PT_F32, exact_f32 != 0): that kernel on v_mfma_f32_16x16x4_f32 with the f32 hidden values themselves
  *     in the granules (the Encodec ENCODER: 15.8 -> 9.3 ms per 32 x 900 frames against the per-step kernels);
- *   - per step (other H, small devices or inputs, PT_LSTM_PERSIST=0 / PT_LSTM_PERSIST_EXACT=0): T + 1 dependent launches (layer 0
- *     step s beside layer 1 step s - 1).
+ *   - per step (other H, small devices or inputs, per_step != 0, PT_LSTM_PERSIST=0 / PT_LSTM_PERSIST_EXACT=0 -- both read per
+ *     call): T + 1 dependent launches (layer 0 step s beside layer 1 step s - 1).
+ * Persistent launches of ONE device are serialised by the library (a per-device event, recorded behind a call's last launch and
+ * waited for -- on the device -- by the next call's first, under a host mutex that covers the enqueue only): two of them
+ * overlapping would each wait for CUs the other holds.  Not applied to a stream under graph capture.
  * `status`: device pointer to ONE 32-bit word owned by the caller, or NULL.  The call clears it on the stream; after the call
  * has completed on the stream, 0 = ok and non-zero = a hand-off of the persistent form timed out (out_elu is then INVALID:
  * copy the word back -- e.g. to pinned memory on the same stream -- and check it before using the result).  With NULL the word is
@@ -372,6 +382,7 @@ typedef struct pt_lstm2_desc {
   int64_t exact_f32;     /* PT_F32: != 0 = the exact f32 MFMA, persistent or per step (the Encodec ENCODER, whose output
                             feeds integer code decisions); 0 = the persistent f32-class form where it applies (bf16 x 3 products:
                             ~1e-5 relative, for the decoder's 1e-3 waveform bound) */
+  int64_t per_step;      /* != 0: the per-step kernels for THIS call (what a caller retries with after a timed-out hand-off) */
 } pt_lstm2_desc;
 int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream);
 

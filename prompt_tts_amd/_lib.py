@@ -64,7 +64,7 @@ class pt_lstm2_desc(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("H", C.c_int64), ("x", C.c_void_p), ("xg0", C.c_void_p),
                 ("whh0", C.c_void_p), ("wcat1", C.c_void_p), ("bias1", C.c_void_p), ("h0_seq", C.c_void_p),
                 ("h1_seq", C.c_void_p), ("c0", C.c_void_p), ("c1", C.c_void_p), ("out_elu", C.c_void_p), ("status", C.c_void_p),
-                ("exact_f32", C.c_int64)]
+                ("exact_f32", C.c_int64), ("per_step", C.c_int64)]
 
 
 class pt_encodec_tail_desc(C.Structure):

@@ -45,10 +45,23 @@ def adamw_state_dict(store, lr, hyper):
 def load_adamw_state_dict(store, sd):
     """Inverse of adamw_state_dict (also accepts the flat private format written by round-1 builds)."""
     dev = store.device
-    if "exp_avg" in sd and "names" in sd:                                   # round-1 flat format
+    if "exp_avg" in sd and "names" in sd:                                   # round-1 flat format: moments in MASTER order
         if sd["names"] != store.names:
             raise RuntimeError("optimizer checkpoint does not match this model's parameter list")
-        store.adam_m = sd["exp_avg"].to(dev).clone(); store.adam_v = sd["exp_avg_sq"].to(dev).clone()
+        # the flat moments are now indexed like the GRADIENT (Conv1d k=3 weights tap-major, [Cout][3][Cin]); a round-1 file holds
+        # them in master order (Cout, Cin, 3): go through the per-parameter views, which permute (copying the buffers verbatim
+        # would silently scramble the moments of every conv k=3 weight)
+        m_old, v_old = sd["exp_avg"].to(dev), sd["exp_avg_sq"].to(dev)
+        if m_old.numel() != store.flat_p.numel() or v_old.numel() != store.flat_p.numel():
+            raise RuntimeError("optimizer checkpoint (flat format) does not match this model's parameter buffer")
+        store.adam_m = torch.zeros_like(store.flat_p); store.adam_v = torch.zeros_like(store.flat_p)
+        for p in store.params_in_model_order():
+            info = store.info[id(p)]
+            if info["frozen"]:
+                continue
+            lo = info["off"]
+            _moment_view(store.adam_m, info, p).copy_(m_old[lo:lo + p.numel()].view(p.shape))
+            _moment_view(store.adam_v, info, p).copy_(v_old[lo:lo + p.numel()].view(p.shape))
         store.step_count = int(sd["step"])
         return
     params = store.params_in_model_order()

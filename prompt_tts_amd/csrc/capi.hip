@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 22; }
+extern "C" int pt_abi_version(void) { return 23; }
 
 thread_local int pt_g_last_hip_error = 0;      // per calling thread: concurrent callers do not overwrite each other's error
 extern "C" const char* pt_last_hip_error(void) { return hipGetErrorString((hipError_t)pt_g_last_hip_error); }

@@ -1,10 +1,48 @@
 // Encodec decoder kernels that do not fit the 128x128 GEMM: RVQ gather-sum, row-streaming conv for few output
 // channels (the 24 kHz end of the SEANet decoder: 16..64 channels, HBM-bound), and the 2-layer LSTM recurrence.
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "mma.h"
 
 namespace {
+
+// ---- one persistent LSTM launch at a time per device ------------------------------------------------------------------------
+// A persistent launch needs every one of its workgroups resident at once (one per CU, the whole register file of the CU): two of
+// them in flight on two streams each wait -- census first, then every hand-off -- for CUs the other one holds, alternate at a
+// crawl (measured: 25.9 ms per decode against 8.0) and, past the spin bound, time out.  The library therefore orders them itself:
+// a call's persistent launches wait (on the DEVICE, hipStreamWaitEvent) for the event the previous call on this device recorded
+// behind its last launch, whatever stream that was.  The host mutex only covers the enqueue (wait, launches, record), so that two
+// host threads cannot interleave their sequences; nothing blocks the host.  A stream that is being captured into a graph is left
+// alone (an event recorded outside the capture cannot be waited for inside it): a captured decode must not be replayed beside
+// another persistent launch -- that stays the caller's rule.
+constexpr int PT_GATE_DEVICES = 64;
+struct PersistGate {
+  std::mutex mu;
+  hipEvent_t ev[PT_GATE_DEVICES] = {};
+  bool have[PT_GATE_DEVICES] = {};
+};
+PersistGate& persist_gate() { static PersistGate g; return g; }
+
+struct PersistTurn {            // RAII: take the device's turn for the launches enqueued while this object lives
+  PersistGate& g; std::unique_lock<std::mutex> lk; int dev; hipStream_t s; bool active;
+  PersistTurn(int device, hipStream_t stream) : g(persist_gate()), lk(g.mu), dev(device), s(stream), active(false) {
+    if (dev < 0 || dev >= PT_GATE_DEVICES) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs != hipStreamCaptureStatusNone) return;
+    if (!g.have[dev]) {
+      if (hipEventCreateWithFlags(&g.ev[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+      g.have[dev] = true;
+    } else if (hipStreamWaitEvent(s, g.ev[dev], 0) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    active = true;
+  }
+  ~PersistTurn() {
+    if (active && hipEventRecord(g.ev[dev], s) != hipSuccess) (void)hipGetLastError();
+  }
+};
 
 // ---- RVQ decode ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -817,8 +855,10 @@ namespace {
 // which costs 3 bf16 MFMAs where the exact-f32 MFMA costs 16.  The 32 x 1536 weights of a workgroup do not fit LDS as hi + lo
 // (192 KiB), but they fit the REGISTER file: the workgroup's four waves split the reduction, and a wave keeps the B fragments
 // of its k-steps for the whole kernel (24 fragments x {hi, lo} = 192 registers per lane; one wave per SIMD may use 512) -- the
-// MFMAs read no LDS at all.  A granule is 16 bytes {hi pair, lo pair, tag, tag}, written by ONE sc1 16-byte store (observed
-// untorn on gfx950; the two tag words catch a torn 8-byte half); a b128 load returns exactly one granule = two hidden units.
+// MFMAs read no LDS at all.  A granule is 16 bytes {hi pair, tag, lo pair, tag} -- ONE TAG IN EACH 8-BYTE HALF, so a 16-byte
+// store or load that the memory system splits at the 8-byte boundary can never show fresh tags over a stale data word (with both
+// tags in the upper half, as rounds 2 - 3 had it, a tear would have passed the check) -- written by ONE 16-byte store; a b128
+// load returns exactly one granule = two hidden units.
 // Input gates, skip connection and output are f32.  The per-step kernels took 17.8 us per tick (T + 1 launches re-reading
 // 12 MiB of f32 weights through L2); see DESIGN.md for the measured tick of this form.
 struct LstmPersist3 {
@@ -827,6 +867,7 @@ struct LstmPersist3 {
   float* out_elu;
   u32x4_t* gx;              // granules [2 parity][2 layer][clusters * 16 rows][256 unit pairs]; zeroed by the launch function
   unsigned* err; int spin_limit; int fault_slice;
+  int fault_half;           // test hook with fault_slice: 0 = both tag words wrong, 1 / 2 = only the first / second 8-byte half's
 };
 
 // slot j <- w[8 (j >> 1) + (j & 1)]: the k-order in which the granule loads of lstm2_persist3_kernel deliver the A operand
@@ -931,10 +972,10 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
         }
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ok &= (v0[i][2] == want) & (v0[i][3] == want);
+        for (int i = 0; i < 16; ++i) ok &= (v0[i][1] == want) & (v0[i][3] == want);
         if (need1) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) ok &= (v1[i][2] == want) & (v1[i][3] == want);
+          for (int i = 0; i < 16; ++i) ok &= (v1[i][1] == want) & (v1[i][3] == want);
         }
         if (__all(ok)) break;
         if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -945,13 +986,13 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
       }
       if constexpr (EXACT) {
         // exact f32 (the encoder: its embeddings feed integer code decisions): a granule carries two f32 hidden values, slot
-        // j = 2 i + c of k-block k is word c of load i, and four lanes g make one K = 4 step of v_mfma_f32_16x16x4_f32
+        // j = 2 i + c of k-block k is word 2 c of load i, and four lanes g make one K = 4 step of v_mfma_f32_16x16x4_f32
         if (!aborted) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float a0 = __uint_as_float(v0[4 * k + (j >> 1)][j & 1]), a1 = __uint_as_float(v1[4 * k + (j >> 1)][j & 1]);
+              const float a0 = __uint_as_float(v0[4 * k + (j >> 1)][2 * (j & 1)]), a1 = __uint_as_float(v1[4 * k + (j >> 1)][2 * (j & 1)]);
               acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][0][j], acc[0], 0, 0, 0);
               acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][1][j], acc[1], 0, 0, 0);
               acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x1a[k][0][j], acc[2], 0, 0, 0);
@@ -965,10 +1006,10 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
         for (int k = 0; k < 4; ++k) {
           Frag<bf16_t> a0h, a0l, a1h, a1l;
           const u32x4_t h0 = {v0[4 * k][0], v0[4 * k + 1][0], v0[4 * k + 2][0], v0[4 * k + 3][0]};
-          const u32x4_t o0 = {v0[4 * k][1], v0[4 * k + 1][1], v0[4 * k + 2][1], v0[4 * k + 3][1]};
+          const u32x4_t o0 = {v0[4 * k][2], v0[4 * k + 1][2], v0[4 * k + 2][2], v0[4 * k + 3][2]};
           a0h.v = __builtin_bit_cast(bf16x8_t, h0); a0l.v = __builtin_bit_cast(bf16x8_t, o0);
           const u32x4_t h1 = {v1[4 * k][0], v1[4 * k + 1][0], v1[4 * k + 2][0], v1[4 * k + 3][0]};
-          const u32x4_t o1 = {v1[4 * k][1], v1[4 * k + 1][1], v1[4 * k + 2][1], v1[4 * k + 3][1]};
+          const u32x4_t o1 = {v1[4 * k][2], v1[4 * k + 1][2], v1[4 * k + 2][2], v1[4 * k + 3][2]};
           a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
           // unconditional (see lstm2_persist8_kernel): v1 is zero while there is no h1; the four accumulators take turns
           mma16(acc[0], a0h, w0h[k][0]); mma16(acc[1], a0h, w0h[k][1]); mma16(acc[2], a0h, w1ah[k][0]); mma16(acc[3], a0h, w1ah[k][1]);
@@ -1003,15 +1044,17 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
       hn = og * tanhf(cstate);
     }
     if (s < p.T) {
-      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
-      //          (EXACT: {f32 of unit jj, f32 of unit jj + 1, tag, tag})
+      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, tag, lo pair, tag}, by the even lane
+      //          (EXACT: {f32 of unit jj, tag, f32 of unit jj + 1, tag})
       const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
       const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
       const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
       const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
       if ((jj & 1) == 0) {
-        const unsigned tag = (unsigned)(s + 1) + ((int)blockIdx.x == p.fault_slice ? 0x40000000u : 0u);
-        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), hn_o, tag, tag} : (u32x4_t){hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        const bool faulty = (int)blockIdx.x == p.fault_slice;       // test hook; fault_half 1 / 2: only that half's tag is wrong
+        const unsigned tag = (unsigned)(s + 1);
+        const unsigned tag_a = tag + (faulty && p.fault_half != 2 ? 0x40000000u : 0u), tag_b = tag + (faulty && p.fault_half != 1 ? 0x40000000u : 0u);
+        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), tag_a, hn_o, tag_b} : (u32x4_t){hi | (hi_o << 16), tag_a, lo | (lo_o << 16), tag_b};
         u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + 16 * c + b)) * 256 + (LP_UNITS * u + jj) / 2;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
       }
@@ -1025,7 +1068,7 @@ __global__ __launch_bounds__(256, 1) void lstm2_persist3_kernel(const LstmPersis
 
 // ---- persistent 2-layer LSTM, f32-class, 8-row clusters on one XCD ------------------------------------------------------------
 // lstm2_persist8_kernel's plan for the f32-class arithmetic of lstm2_persist3_kernel (bf16 x 3 products, 16-byte granules
-// {hi pair, lo pair, tag, tag}): clusters of 8 rows x 32 workgroups, cluster = XCD where the census allows it.  A workgroup's 16
+// {hi pair, tag, lo pair, tag}): clusters of 8 rows x 32 workgroups, cluster = XCD where the census allows it.  A workgroup's 16
 // units x 4 gates x 1536 inputs are 384 KiB of hi + lo weights: EIGHT waves split the reduction (two 32-unit k-blocks of h0 and
 // of h1 each), a wave keeps 36 of its 48 B fragments in registers (144 per lane) and twelve lo fragments -- the h1 part's eight and
 // the second k-block's four of layer 1's h0 part -- in LDS (96 KiB per workgroup): 248 registers per lane, no spills, at the two
@@ -1038,6 +1081,7 @@ struct LstmPersist8f {
   u32x4_t* gx;              // granules [2 parity][2 layer][clusters * 8 rows][256 unit pairs]; zeroed by the launch function
   unsigned* err; int spin_limit; int fault_slice;
   unsigned* census; int force_remote;
+  int fault_half;           // see LstmPersist3
 };
 constexpr int L8F_WAVES = 8;
 
@@ -1166,12 +1210,12 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
       bool aborted = false;
       for (;;) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i] = (u32x4_t){0u, 0u, want, want}; v1[i] = (u32x4_t){0u, 0u, want, want}; }
+        for (int i = 0; i < 4; ++i) { v0[i] = (u32x4_t){0u, want, 0u, want}; v1[i] = (u32x4_t){0u, want, 0u, want}; }
         if (local) l8f_load<2>(v0, v1, grs, voff0, voff1, need1);
         else l8f_load<16>(v0, v1, grs, voff0, voff1, need1);
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ok &= (v0[i][2] == want) & (v0[i][3] == want) & (v1[i][2] == want) & (v1[i][3] == want);
+        for (int i = 0; i < 4; ++i) ok &= (v0[i][1] == want) & (v0[i][3] == want) & (v1[i][1] == want) & (v1[i][3] == want);
         if (__all(ok)) break;
         if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           if (lane == 0) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abort_flag = 1; }
@@ -1185,8 +1229,8 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
           for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              // slot j: granule j >> 1 of the lane's four (own line 0, lane li + 8's line 0, own line 1, lane li + 8's line 1), word j & 1
-              const unsigned r0 = v0[2 * k + (j >> 2)][j & 1], r1 = v1[2 * k + (j >> 2)][j & 1];
+              // slot j: granule j >> 1 of the lane's four (own line 0, lane li + 8's line 0, own line 1, lane li + 8's line 1), word 2 (j & 1)
+              const unsigned r0 = v0[2 * k + (j >> 2)][2 * (j & 1)], r1 = v1[2 * k + (j >> 2)][2 * (j & 1)];
               const float a0 = __uint_as_float(((j >> 1) & 1) ? l8_from_upper(r0) : r0), a1 = __uint_as_float(((j >> 1) & 1) ? l8_from_upper(r1) : r1);
 #pragma unroll
               for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[k][tl][j], acc[tl], 0, 0, 0);
@@ -1205,12 +1249,12 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
       if (!aborted) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          // slots (0,1) own line 0, (2,3) lane li + 8's line 0, (4,5) own line 1, (6,7) lane li + 8's line 1; word 0 = hi pair, 1 = lo pair
+          // slots (0,1) own line 0, (2,3) lane li + 8's line 0, (4,5) own line 1, (6,7) lane li + 8's line 1; word 0 = hi pair, 2 = lo pair
           Frag<bf16_t> a0h, a0l, a1h, a1l;
           const u32x4_t h0 = {v0[2 * k][0], l8_from_upper(v0[2 * k][0]), v0[2 * k + 1][0], l8_from_upper(v0[2 * k + 1][0])};
-          const u32x4_t o0 = {v0[2 * k][1], l8_from_upper(v0[2 * k][1]), v0[2 * k + 1][1], l8_from_upper(v0[2 * k + 1][1])};
+          const u32x4_t o0 = {v0[2 * k][2], l8_from_upper(v0[2 * k][2]), v0[2 * k + 1][2], l8_from_upper(v0[2 * k + 1][2])};
           const u32x4_t h1 = {v1[2 * k][0], l8_from_upper(v1[2 * k][0]), v1[2 * k + 1][0], l8_from_upper(v1[2 * k + 1][0])};
-          const u32x4_t o1 = {v1[2 * k][1], l8_from_upper(v1[2 * k][1]), v1[2 * k + 1][1], l8_from_upper(v1[2 * k + 1][1])};
+          const u32x4_t o1 = {v1[2 * k][2], l8_from_upper(v1[2 * k][2]), v1[2 * k + 1][2], l8_from_upper(v1[2 * k + 1][2])};
           a0h.v = __builtin_bit_cast(bf16x8_t, h0); a0l.v = __builtin_bit_cast(bf16x8_t, o0);
           a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
 #pragma unroll
@@ -1273,14 +1317,16 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
       }
     }
     if (gater && s < p.T) {
-      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, lo pair, tag, tag}, by the even lane
+      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, tag, lo pair, tag}, by the even lane
       const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
       const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
       const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
       const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
       if ((jj & 1) == 0) {
-        const unsigned tag = (unsigned)(s + 1) + (c * L8_SLICES + u == p.fault_slice ? 0x40000000u : 0u);
-        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), hn_o, tag, tag} : (u32x4_t){hi | (hi_o << 16), lo | (lo_o << 16), tag, tag};
+        const bool faulty = c * L8_SLICES + u == p.fault_slice;     // test hook; fault_half 1 / 2: only that half's tag is wrong
+        const unsigned tag = (unsigned)(s + 1);
+        const unsigned tag_a = tag + (faulty && p.fault_half != 2 ? 0x40000000u : 0u), tag_b = tag + (faulty && p.fault_half != 1 ? 0x40000000u : 0u);
+        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), tag_a, hn_o, tag_b} : (u32x4_t){hi | (hi_o << 16), tag_a, lo | (lo_o << 16), tag_b};
         u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
         if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
@@ -1832,7 +1878,9 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   // clusters <= CUs / 64 -- a partitioned (CPX), CU-masked or smaller device gets fewer clusters per launch, or the per-step
   // kernels.  A lost hand-off (e.g. another stream's LDS-heavy kernels holding CUs for longer than the spin bound) ends the
   // launch early with the status word set: pt_lstm2_desc.status, which the caller must read before it trusts out_elu.
-  static const int persist = pt_env_int("PT_LSTM_PERSIST", 1);
+  // PT_LSTM_PERSIST=0 (read per call, never cached) or pt_lstm2_desc.per_step: the per-step kernels for this call -- what a caller
+  // retries with after a timed-out hand-off, in the same process
+  const int persist = pt_env_int("PT_LSTM_PERSIST", 1) && !d->per_step;
   unsigned* status = d->status ? reinterpret_cast<unsigned*>(d->status) : reinterpret_cast<unsigned*>(d->h0_seq);
   if (d->status && hipMemsetAsync(d->status, 0, 4, s) != hipSuccess) return PT_ERR_LAUNCH;
   int cus = 0, device = 0;
@@ -1845,6 +1893,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
     // test hooks, read per call (never cached): a short spin bound and a workgroup that publishes wrong tags
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = L8_ROWS * max_clusters8;
+    PersistTurn turn(device, s);
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
       LstmPersist q;
       q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
@@ -1872,12 +1921,13 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
     return PT_OK;
   }
   // f32-class (the decoder at the reference's precision): 8-row clusters on one XCD each (lstm2_persist8f_kernel) ...
-  static const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
+  const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
   const int rows8f = pt_env_int("PT_LSTM_F32_ROWS8", 1);              // read per call: tests compare the forms
   const int64_t ws_need8f = 512 + 2ll * 2 * 64 * 256 * 16;
   if (persist && (d->exact_f32 ? pt_env_int("PT_LSTM_PERSIST_EXACT", 1) : persist3) && rows8f && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = L8_ROWS * max_clusters8;
+    PersistTurn turn(device, s);
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
       LstmPersist8f q;
       q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
@@ -1891,6 +1941,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       q.force_remote = pt_env_int("PT_LSTM_FORCE_REMOTE", 0);
       q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
       q.fault_slice = e_fault ? atoi(e_fault) : -1;
+      q.fault_half = pt_env_int("PT_LSTM_DEBUG_FAULT_HALF", 0);
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
@@ -1907,6 +1958,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   if (persist && (d->exact_f32 ? persist_exact : persist3) && max_clusters >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need3) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = 16 * max_clusters;
+    PersistTurn turn(device, s);
     for (int64_t b0 = 0; b0 < d->B; b0 += rows_per_launch) {
       LstmPersist3 q;
       q.B = (int)d->B; q.T = (int)d->T; q.b_base = (int)b0;
@@ -1918,6 +1970,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       q.gx = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(d->h0_seq) + 256);
       q.spin_limit = e_spin ? atoi(e_spin) : (1 << 20);
       q.fault_slice = e_fault ? atoi(e_fault) : -1;
+      q.fault_half = pt_env_int("PT_LSTM_DEBUG_FAULT_HALF", 0);
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 2ll * 2 * q.clusters * 16 * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;

@@ -66,16 +66,28 @@ def _pad_cols(m, mult):
 _SKIP_STATUS_CHECK = __import__("os").environ.get("PT_LSTM_CHECK", "1") == "0"
 
 
+class LstmTimeout(RuntimeError):
+    pass
+
+
+def _retry_enabled():
+    """PT_LSTM_RETRY=0 (read per call): raise at the first timed-out hand-off instead of retrying with the per-step kernels."""
+    return __import__("os").environ.get("PT_LSTM_RETRY", "1") != "0"
+
+
 class LstmStatus:
     """The status word of pt_lstm2_forward (include/prompt_tts_hip.h): cleared by the call, set by the persistent kernel when a
     hand-off between its workgroups timed out (not all of them resident, e.g. another stream's kernels holding CUs) -- the
     output is then garbage.  The word is copied to pinned host memory ON THE STREAM right behind the LSTM, so the rest of the
-    decoder is enqueued without a stall; check() waits for that copy only and raises instead of returning a wrong waveform."""
+    decoder is enqueued without a stall; check() waits for that copy only and raises instead of returning a wrong waveform.
+    One object serves ONE call at a time: `busy` is set when a call takes it and cleared by check(); a decoder hands a second,
+    overlapping call (another host thread / stream) its own object instead of this one (_StatusPool)."""
 
     def __init__(self, device):
         self.dev_word = torch.zeros(1, dtype=torch.int32, device=device)
         self.host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.event = torch.cuda.Event()
+        self.busy = False
 
     def ptr(self):
         return self.dev_word.data_ptr()
@@ -84,19 +96,47 @@ class LstmStatus:
         self.host_word.copy_(self.dev_word, non_blocking=True)
         self.event.record(torch.cuda.current_stream(self.dev_word.device))
 
+    def failed(self):
+        """Waits for the copy of the word; True = a hand-off timed out.  Releases the object."""
+        try:
+            if _SKIP_STATUS_CHECK:       # PT_LSTM_CHECK=0: timing diagnostic only (tools/decode_probe.py)
+                return False
+            self.event.synchronize()
+            return int(self.host_word[0]) != 0
+        finally:
+            self.busy = False
+
     def check(self):
-        if _SKIP_STATUS_CHECK:           # PT_LSTM_CHECK=0: timing diagnostic only (tools/decode_probe.py)
-            return
-        self.event.synchronize()
-        if int(self.host_word[0]) != 0:
-            raise RuntimeError("pt_lstm2_forward: a hand-off of the persistent LSTM timed out (its workgroups were not all "
-                               "resident: is another stream holding CUs?); the result was discarded -- retry, or set "
-                               "PT_LSTM_PERSIST=0 for the per-step kernels")
+        if self.failed():
+            raise LstmTimeout("pt_lstm2_forward: a hand-off of the persistent LSTM timed out (its workgroups were not all "
+                              "resident: is a kernel of another library holding CUs?) and so did the retry; the result was "
+                              "discarded")
 
 
-def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None, exact_f32=False):
+class _StatusPool:
+    """Status words of one decoder / encoder: a call takes a free one (allocating a pinned word is slow, so they are kept) and
+    gives it back in check().  Two overlapping calls on one object therefore never share a word -- round 3's silent failure:
+    call B's clearing memset wiped the time-out call A's kernel had just raised, and A returned a garbage waveform."""
+
+    def __init__(self, device):
+        self.device, self.items, self.lock = device, [], __import__("threading").Lock()
+
+    def take(self):
+        with self.lock:
+            for st in self.items:
+                if not st.busy:
+                    st.busy = True
+                    return st
+            st = LstmStatus(self.device)
+            st.busy = True
+            self.items.append(st)
+            return st
+
+
+def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None, exact_f32=False, per_step=False):
     """Two-layer LSTM + skip + ELU over (B*T, 512) token-major rows; returns (ELU(h1 + x), LstmStatus to check()).
-    `status`: a reusable LstmStatus (pinned allocation is slow); it must have been check()ed since its last use."""
+    `status`: a reusable LstmStatus (pinned allocation is slow) that no other call is using.  per_step: the per-step kernels
+    (the retry after a timed-out hand-off of the persistent form).  Every scratch buffer is allocated per call."""
     M = B * T
     h0 = torch.empty(M, 512, dtype=dtype, device=device); h1 = torch.empty_like(h0); ze = torch.empty_like(h0)
     c0 = torch.empty(B, 512, dtype=torch.float32, device=device); c1 = torch.empty_like(c0)
@@ -107,6 +147,7 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None,
     ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h1.data_ptr(), c0.data_ptr(), c1.data_ptr(), ze.data_ptr()
     ld.status = st.ptr()
     ld.exact_f32 = int(exact_f32)      # the encoder: its embeddings feed integer code decisions -> exact f32 MFMA
+    ld.per_step = int(per_step)
     check(lib.pt_lstm2_forward(C.byref(ld), pt, ops._stream()), "pt_lstm2_forward")
     st.fetch()
     return ze, st
@@ -158,10 +199,10 @@ class EncodecDecoder:
 
     # -- helpers --------------------------------------------------------------------------------------------------
     def _lstm_status(self):
-        st = getattr(self, "_lstm_st", None)
-        if st is None:
-            st = self._lstm_st = LstmStatus(self.device)
-        return st
+        pool = getattr(self, "_lstm_pool", None)
+        if pool is None:
+            pool = self._lstm_pool = _StatusPool(self.device)
+        return pool.take()
 
     def _rowconv(self, Bn, n_rows, x, cin, taps, rowmap, w, bias, N, y, act=0, elu_x=0, x2=None, cin2=0, elu_x2=0, y_f32=False):
         d = L.pt_rowconv_desc()
@@ -181,13 +222,19 @@ class EncodecDecoder:
     @torch.no_grad()
     def decode(self, codes):
         """codes (B, n_q, T) int64 in [0,1023] -> wav (B, 1, 320*T) f32.
-        One call at a time per decoder AND per GPU: the persistent LSTM wants every CU of the device for the length of its launch
-        (two of them in flight on two streams alternate at a crawl) and the decoder owns one status word."""
+        May be called from several host threads / streams at once: every scratch buffer and the status word belong to the call,
+        and the library runs the persistent LSTM launches of one GPU one after the other (include/prompt_tts_hip.h) -- overlapping
+        decodes therefore cost what sequential ones cost; more throughput = more GPUs.  A hand-off that times out anyway (kernels
+        of another library holding CUs) is retried ONCE with the per-step kernels before anything is raised."""
         wav, lstm_status = self._decode(codes)
-        lstm_status.check()              # never hand out a waveform computed from a timed-out recurrence
+        if not _retry_enabled():
+            lstm_status.check()
+        elif lstm_status.failed():       # never hand out a waveform computed from a timed-out recurrence
+            wav, lstm_status = self._decode(codes, per_step=True)
+            lstm_status.check()
         return wav
 
-    def _decode(self, codes):
+    def _decode(self, codes, per_step=False):
         if codes.dim() != 3:
             raise BaseException("The encoded_frames must have the shape of [B, N_q, T]")
         if codes.shape[1] != self.n_q:
@@ -204,7 +251,8 @@ class EncodecDecoder:
         ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0), y0, pt, bias=self.b0, x3=self.x3)
         xg0 = self._empty(M, 2048)
         ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0, x3=self.x3)
-        ze, lstm_status = run_lstm2(B, T, y0, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status())
+        ze, lstm_status = run_lstm2(B, T, y0, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status(),
+                                    per_step=per_step)
         xe, n = ze, T                     # xe = ELU(stage input), n = rows per batch item
         fuse_tail = (self.dtype == torch.bfloat16 and FUSED_TAIL and
                      (self.stages[-1]["r"], self.stages[-1]["cin"], self.stages[-1]["cout"]) == (2, 64, 32) and n * 160 >= 8)
@@ -358,7 +406,17 @@ class EncodecEncoder:
 
     @torch.no_grad()
     def embeddings(self, wav):
-        """wav (B, 1, L) f32, L a multiple of 320 -> (B*T, 128) f32 token-major embeddings, T = L / 320."""
+        """wav (B, 1, L) f32, L a multiple of 320 -> (B*T, 128) f32 token-major embeddings, T = L / 320.
+        A timed-out hand-off of the persistent LSTM is retried once with the per-step kernels (see EncodecDecoder.decode)."""
+        emb, B, T, st = self._embeddings(wav)
+        if not _retry_enabled():
+            st.check()
+        elif st.failed():
+            emb, B, T, st = self._embeddings(wav, per_step=True)
+            st.check()
+        return emb, B, T
+
+    def _embeddings(self, wav, per_step=False):
         if wav.dim() != 3 or wav.shape[1] != 1:
             raise ValueError("wav must be (B, 1, L)")
         B, _, Ln = wav.shape
@@ -399,12 +457,11 @@ class EncodecEncoder:
         xg0 = self._empty(M, 2048)
         ops.gemm(M, 2048, 512, ops.plain(cur), ops.plain(self.w_ih0), xg0, pt, bias=self.bias0)
         ze, lstm_status = run_lstm2(B, T, cur, xg0, self.w_hh0, self.wcat1, self.bias1, pt, self.device, self.dtype, self._lstm_status(),
-                                    exact_f32=True)
+                                    exact_f32=True, per_step=per_step)
         emb = torch.empty(M, 128, dtype=torch.float32, device=self.device)
         ops.gemm(M, 128, 7 * 512, ops.conv(ze, 512, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.wfin), emb, pt,
                  bias=self.bfin, out_kind=L.PT_OUT_F32 if self.dtype != torch.float32 else L.PT_OUT_T)
-        lstm_status.check()
-        return emb, B, T
+        return emb, B, T, lstm_status
 
     @torch.no_grad()
     def quantize(self, emb, B, T):

@@ -161,6 +161,8 @@ class ShardedGradReducer(GradReducer):
             if shard:
                 body = self.flat[lo:tail_lo]
                 mine = body[self.rank * shard:(self.rank + 1) * shard]
+                # the in-place contract of the collective (NCCL / RCCL): the output is exactly slice `rank` of the input
+                assert mine.data_ptr() == body.data_ptr() + self.rank * shard * 4 and mine.numel() == shard
                 w = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.pg, async_op=not self.cuda)
                 if not self.cuda:
                     self._work.append(w)

@@ -363,8 +363,10 @@ def test_hip_encoder_bf16_embeddings(dev):
 def test_persistent_lstm_timeout_raises_instead_of_returning_garbage(dev, monkeypatch):
     """VERDICT r02 / ADVICE r02: a lost hand-off of the persistent LSTM (its workgroups not all resident) used to return a garbage
     waveform with PT_OK.  Force the timeout branch -- the workgroup in role (cluster 0, slice 5) publishes wrong tags, the spin bound is shrunk so that the
-    launch gives up after a few milliseconds -- and require decode() to RAISE; then decode again without the fault: the status
-    word is cleared per call and the result is the good one."""
+    launch gives up after a few milliseconds.  With PT_LSTM_RETRY=0 decode() must RAISE; by default it retries the call once with
+    the per-step kernels (pt_lstm2_desc.per_step; ADVICE r03: a running process could not switch forms) and returns a waveform
+    that matches the good one to the rounding of another summation order; then decode again without the fault: the status word is
+    per call and the result is bit-identical to the first."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
     W = oe.random_weights(5)
@@ -373,9 +375,14 @@ def test_persistent_lstm_timeout_raises_instead_of_returning_garbage(dev, monkey
     good = dec.decode(codes).cpu()
     monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
     monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "5")
+    monkeypatch.setenv("PT_LSTM_RETRY", "0")
     with pytest.raises(RuntimeError, match="timed out"):
         dec.decode(codes)
     torch.cuda.synchronize()
+    monkeypatch.delenv("PT_LSTM_RETRY")
+    retried = dec.decode(codes).cpu()                                 # timed out, then the per-step kernels
+    assert torch.isfinite(retried).all()
+    assert float((retried - good).abs().max()) < 3e-2 * float(good.abs().max())
     monkeypatch.delenv("PT_LSTM_DEBUG_SPIN"); monkeypatch.delenv("PT_LSTM_DEBUG_FAULT_SLICE")
     again = dec.decode(codes).cpu()
     assert torch.equal(again, good)
@@ -391,6 +398,7 @@ def test_persistent_lstm_timeout_in_a_later_launch_of_the_call_is_sticky(dev, mo
     codes = torch.randint(0, 1024, (70, 8, 40), generator=torch.Generator().manual_seed(4)).to(dev)
     monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
     monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "70")
+    monkeypatch.setenv("PT_LSTM_RETRY", "0")
     with pytest.raises(RuntimeError, match="timed out"):
         dec.decode(codes)
     torch.cuda.synchronize()
@@ -419,16 +427,62 @@ def test_persistent_f32_lstm_decoder_vs_oracle(dev, B, T, form, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_persistent_f32_lstm_timeout_raises(dev, monkeypatch):
+@pytest.mark.parametrize("half", [0, 1, 2])
+def test_persistent_f32_lstm_timeout_raises(dev, half, monkeypatch):
+    """ADVICE r03: the 16-byte granules of the f32-class / exact-f32 kernels carry one tag PER 8-BYTE HALF ({data, tag, data, tag});
+    a granule whose first (half = 1) or second (half = 2) half alone is stale -- what a 16-byte access split at the 8-byte boundary
+    would show -- must fail the consumers' check exactly like one with both tags wrong (half = 0).  By default the call is then
+    retried with the per-step kernels and matches the oracle."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
-    dec = EncodecDecoder(oe.random_weights(5), device=dev, dtype=torch.float32)
+    W = oe.random_weights(5)
+    dec = EncodecDecoder(W, device=dev, dtype=torch.float32)
     codes = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(3)).to(dev)
     monkeypatch.setenv("PT_LSTM_DEBUG_SPIN", "2000")
     monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_SLICE", "5")
+    monkeypatch.setenv("PT_LSTM_DEBUG_FAULT_HALF", str(half))
+    monkeypatch.setenv("PT_LSTM_RETRY", "0")
     with pytest.raises(RuntimeError, match="timed out"):
         dec.decode(codes)
     torch.cuda.synchronize()
+    if half == 1:
+        monkeypatch.delenv("PT_LSTM_RETRY")
+        got = dec.decode(codes).cpu()
+        want = oe.decode(codes[:2].cpu(), W)
+        assert float((got[:2] - want).abs().max()) < 1e-3 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_two_decoders_on_two_streams_equal_the_sequential_decodes(dev):
+    """VERDICT r03 item 2 (the run that wrote nothing for 420 s, and three overlapping decodes that returned DIFFERENT waveforms
+    without an error): two decoders -- and two calls on ONE decoder -- enqueued on two streams at once.  The library orders the
+    persistent LSTM launches of a device itself and every call owns its scratch and status word, so the results must be the
+    bits of the sequential decodes.  Run once, small T."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecDecoder
+    W = oe.random_weights(5)
+    d1 = EncodecDecoder(W, device=dev, dtype=torch.bfloat16)
+    d2 = EncodecDecoder(W, device=dev, dtype=torch.float32)
+    c1 = torch.randint(0, 1024, (20, 8, 150), generator=torch.Generator().manual_seed(1)).to(dev)
+    c2 = torch.randint(0, 1024, (24, 8, 140), generator=torch.Generator().manual_seed(2)).to(dev)
+    want1, want2, want3 = d1.decode(c1).clone(), d2.decode(c2).clone(), d1.decode(c2).clone()
+    torch.cuda.synchronize()
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {}
+    import threading
+
+    def work(key, dec, codes, stream):
+        with torch.cuda.stream(stream):
+            outs[key] = dec.decode(codes)
+        stream.synchronize()
+    th = [threading.Thread(target=work, args=a) for a in (("a", d1, c1, s1), ("b", d2, c2, s2), ("c", d1, c2, s3))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["a"], want1) and torch.equal(outs["b"], want2) and torch.equal(outs["c"], want3)
 
 
 @pytest.mark.gpu

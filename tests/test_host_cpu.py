@@ -291,6 +291,33 @@ def test_async_checkpoint_writer_and_adamw_state_dict_format(tmp_path):
         w.wait()
 
 
+def test_flat_format_optimizer_checkpoint_permutes_conv_moments():
+    """the flat Adam moments are indexed like the gradient (Conv1d k=3 weights tap-major [Cout][3][Cin]); a round-1
+    flat-format file holds them in master order (Cout, Cin, 3).  Loading one must land every conv moment at its gradient-order
+    place (what the torch-format path does through _moment_view), not copy the buffer verbatim."""
+    from types import SimpleNamespace
+    from prompt_tts_amd import checkpoint
+    conv = torch.nn.Conv1d(4, 2, 3); lin = torch.nn.Linear(4, 3)
+    params = [conv.weight, conv.bias, lin.weight]
+    info, off = {}, 0
+    for p, name in zip(params, ("c.w", "c.b", "l.w")):
+        info[id(p)] = {"off": off, "n": p.numel(), "frozen": False, "name": name}; off += 64
+    store = SimpleNamespace(info=info, adam_m=None, adam_v=None, step_count=0, device=torch.device("cpu"), flat_p=torch.zeros(off),
+                            names=["c.w", "c.b", "l.w"], params_in_model_order=lambda: params)
+    m_master = torch.arange(off, dtype=torch.float32)
+    checkpoint.load_adamw_state_dict(store, {"names": ["c.w", "c.b", "l.w"], "exp_avg": m_master, "exp_avg_sq": m_master * 3, "step": 5})
+    assert store.step_count == 5
+    want = m_master[:24].view(2, 4, 3)                                       # the file: (Cout, Cin, 3)
+    got = store.adam_m[:24].view(2, 3, 4)                                    # the store: [Cout][3][Cin]
+    assert torch.equal(got, want.permute(0, 2, 1)) and not torch.equal(store.adam_m[:24], m_master[:24])
+    assert torch.equal(store.adam_m[64:66], m_master[64:66]) and torch.equal(store.adam_v[128:140], 3 * m_master[128:140])
+    # and it agrees with the torch-format path
+    sd = checkpoint.adamw_state_dict(store, 1e-5, dict(lr=1e-5, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8))
+    assert torch.equal(sd["state"][0]["exp_avg"], want)
+    with pytest.raises(RuntimeError):
+        checkpoint.load_adamw_state_dict(store, {"names": ["c.w", "c.b", "l.w"], "exp_avg": m_master[:10], "exp_avg_sq": m_master[:10], "step": 5})
+
+
 def test_wgrad_queue_deferred_problems_never_share_a_launch_with_their_partner(monkeypatch):
     """engine._WgradQueue: a deferred problem (the boundary corrections of a flat conv weight gradient accumulate into the same
     destination as their conv; one launch's fold adds partials with plain read-modify-writes) joins the NEXT group of its class,
