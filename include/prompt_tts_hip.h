@@ -35,7 +35,13 @@ typedef void* pt_stream;            /* a hipStream_t */
 
 enum pt_status { PT_OK = 0, PT_ERR_SHAPE = -1, PT_ERR_DTYPE = -2, PT_ERR_LAUNCH = -3, PT_ERR_ALIGN = -4,
                  PT_ERR_ARG = -5 };
-enum pt_dtype { PT_F32 = 0, PT_BF16 = 1 };
+enum pt_dtype { PT_F32 = 0, PT_BF16 = 1,
+                PT_BF16X2 = 2 };    /* f32-class SPLIT storage for inference at the reference's fp32 precision (decode_codec.py:12-16):
+                                       an element x is the bf16 pair hi = bf16(x), lo = bf16(x - hi); a row of C elements is stored
+                                       [C hi | C lo] (2 C bf16, the bytes of C f32).  Products are bf16 x 3 splits on the bf16 MFMA
+                                       (a_hi b_hi + a_hi b_lo + a_lo b_hi, error ~2^-16), accumulation / bias / ELU in f32.  The
+                                       producer splits once; consumer loops hold no conversion.  Accepted by pt_gemm (forward),
+                                       pt_rvq_decode, pt_lstm2_forward, pt_encodec_res / _stage / _tail only. */
 enum pt_fp8_format { PT_FP8_E4M3 = 0, PT_FP8_E5M2 = 1 };   /* OCP fp8: e4m3 "fn" (max 448), e5m2 (max 57344) */
 
 int pt_abi_version(void);                       /* bumps on any signature change */
@@ -119,8 +125,16 @@ typedef struct pt_gemm_desc {
   int64_t geglu_rows;            /* pt_wgrad_group only, or 0: F > 0 = the M = 2F rows of this weight gradient are in the
                                     interleaved order of act = 2 (A = d(projection) as written by act = 3); C and arow_sum are
                                     written in the ORIGINAL row order                                                       */
+  int64_t x2_block;              /* PT_BF16X2 only, or 0 (= N): the output's plane blocking P -- column n of C / C2 is stored at
+                                    (n / P) 2P + n % P (hi) and P further (lo).  P = cout for a transposed conv whose N = r cout
+                                    columns are viewed as r rows of [cout hi | cout lo] by the next layer                   */
 } pt_gemm_desc;
 
+/* dtype PT_BF16X2 (forward GEMMs of f32-class inference; Encodec decode at the reference's fp32 precision): K, N, cin, c_split
+ * count LOGICAL elements; every operand row holds its hi plane followed by its lo plane -- A: PT_V_PLAIN [M][>= 2K] (lo at + K),
+ * PT_V_CONCAT (p: lo at + c_split, p2: lo at + K - c_split), PT_V_CONV (rows of [cin hi | cin lo]); B: PT_V_PLAIN [N][>= 2K];
+ * the kernel is the bf16 GEMM over 3 K columns (A copies {hi, hi, lo}, B copies {hi, lo, hi}).  Outputs: PT_OUT_T = plane rows
+ * (ldc >= 2N, see x2_block), PT_OUT_F32 = plain f32.  bias / act 0-1 / C2 + act2; no residuals, transposes or split-K. */
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
 
 /* Grouped weight gradients (bf16): up to 8 GEMMs dW_i (+)= alpha_i dY_i^T X_i in ONE launch + one fold launch.
@@ -322,7 +336,8 @@ int pt_pack_shadow(const float* p, void* shadow, const pt_param_seg* seg_dev, in
  * Big layers (conv k7 128->512, the transposed convs, the C>=128 residual blocks) run on pt_gemm with the
  * PT_MAP_CAUSAL_REFLECT / PT_MAP_BACK row maps; the kernels below cover what a 128x128 GEMM tile cannot.
  * ---------------------------------------------------------------------------------------------- */
-/* RVQ decode: out[(b,t)][:] = sum_q codebooks[q][codes[b][q][t]][:]   (codes int64 (B,n_q,T); dim multiple of 8). */
+/* RVQ decode: out[(b,t)][:] = sum_q codebooks[q][codes[b][q][t]][:]   (codes int64 (B,n_q,T); dim multiple of 8).
+ * PT_BF16X2: codebooks f32, out rows [dim hi | dim lo] bf16. */
 int pt_rvq_decode(const int64_t* codes, const void* codebooks, void* out, int64_t B, int64_t n_q, int64_t T,
                   int64_t bins, int64_t dim, int dtype, pt_stream stream);
 
@@ -374,6 +389,9 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  * has completed on the stream, 0 = ok and non-zero = a hand-off of the persistent form timed out (out_elu is then INVALID:
  * copy the word back -- e.g. to pinned memory on the same stream -- and check it before using the result).  With NULL the word is
  * the first 32 bits of h0_seq.  Latency-bound: reports steps/s, not a roofline fraction. */
+/* PT_BF16X2: x and out_elu are plane rows [H hi | H lo] bf16; xg0, the weights and the scratch buffers are as for PT_F32
+ * (h0_seq: B*T*H*4 bytes); only the persistent f32-class form exists -- where it does not apply (small inputs / devices,
+ * per_step, exact_f32) the call returns PT_ERR_SHAPE and the caller converts and takes PT_F32. */
 typedef struct pt_lstm2_desc {
   int64_t B, T, H;
   const void* x; const void* xg0; const void* whh0; const void* wcat1; const float* bias1;
@@ -397,6 +415,9 @@ typedef struct pt_encodec_tail_desc {
   const void* wt; const float* bt; const void* w3; const float* b3; const void* wf; const float* bf; const void* wfin; const float* bfin;
   float* wav;
 } pt_encodec_tail_desc;
+/* PT_BF16X2 (all three fused kernels; csrc/encodec_x2.hip): x / y are plane rows ([cin hi | cin lo], ldx >= 2 cin; y likewise
+ * over cout), the weight pointers are F32 matrices of the same [rows][K] shapes (wf of the tail: [32][64] with 48 used), split
+ * into hi / lo fragments once per workgroup; intermediates live in LDS as planes, products are bf16 x 3. */
 int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stream stream);
 
 /* Fused decoder stage (bf16) for (cin, cout, r) = (128, 64, 4): transposed conv + residual block (conv k3 cout -> cout/2, 1x1 +

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PT_TTS_LIB: another build of the SAME library (tests load the host-sanitizer build, csrc `make asan`, this way)
 LIB_PATH = os.environ.get("PT_TTS_LIB") or os.path.join(_HERE, "libprompt_tts_hip.so")
 
-PT_F32, PT_BF16 = 0, 1
+PT_F32, PT_BF16, PT_BF16X2 = 0, 1, 2
 PT_FP8_E4M3, PT_FP8_E5M2 = 0, 1
 PT_FP8_STATE_FLOATS = 258
 PT_V_PLAIN, PT_V_CONCAT, PT_V_CONV, PT_V_WFLIP = 0, 1, 2, 3
@@ -39,7 +39,7 @@ class pt_gemm_desc(C.Structure):
                 ("conv_wgrad_cin_store", C.c_int32), ("alpha", C.c_float), ("act", C.c_int32), ("act2", C.c_int32),
                 ("C2", C.c_void_p), ("ldc2", C.c_int64),
                 ("arow_sum", C.c_void_p), ("arow_n", C.c_int64), ("arow_stride", C.c_int64), ("arow_rep", C.c_int32),
-                ("f32_x3", C.c_int32), ("geglu_rows", C.c_int64)]
+                ("f32_x3", C.c_int32), ("geglu_rows", C.c_int64), ("x2_block", C.c_int64)]
 
 
 class pt_attn_desc(C.Structure):

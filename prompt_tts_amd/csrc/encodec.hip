@@ -71,6 +71,36 @@ __global__ __launch_bounds__(256) void rvq_kernel(const int64_t* __restrict__ co
   }
 }
 
+// PT_BF16X2: f32 codebooks summed in f32, the row written as [dim hi | dim lo] bf16 planes (encodec_x2.hip)
+__global__ __launch_bounds__(256) void rvq_x2_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb,
+                                                     bf16_t* __restrict__ out, int64_t B, int nq, int64_t Tn, int bins, int dim) {
+  const int cpr = dim / 8;
+  const int64_t total = B * Tn * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t bt = i / cpr; const int c = (int)(i - bt * cpr) * 8;
+    const int64_t b = bt / Tn, t = bt - b * Tn;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int q = 0; q < nq; ++q) {
+      int64_t idx = codes[(b * nq + q) * Tn + t];
+      idx = idx < 0 ? 0 : (idx >= bins ? bins - 1 : idx);
+      const float* src = cb + ((int64_t)q * bins + idx) * dim + c;
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src), v1 = *reinterpret_cast<const f32x4_t*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[e] += v0[e]; acc[4 + e] += v1[e]; }
+    }
+    u32x4_t hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = pack_bf16x2(acc[2 * k], acc[2 * k + 1]);
+      lo[k] = pack_bf16x2(acc[2 * k] - __uint_as_float(hi[k] << 16), acc[2 * k + 1] - __uint_as_float(hi[k] & 0xffff0000u));
+    }
+    *reinterpret_cast<u32x4_t*>(out + bt * 2 * dim + c) = hi;
+    *reinterpret_cast<u32x4_t*>(out + bt * 2 * dim + dim + c) = lo;
+  }
+}
+
 // ---- RVQ encode: one stage of the nearest-codeword search (one wave per token) -------------------------------
 __global__ __launch_bounds__(256) void rvq_search_kernel(const float* __restrict__ scores, const float* __restrict__ cb,
                                                          float* __restrict__ residual, int64_t* __restrict__ codes,
@@ -1097,7 +1127,8 @@ __device__ __forceinline__ void l8f_load(u32x4_t (&v0)[4], u32x4_t (&v1)[4], __a
 
 // EXACT: f32 weights, f32 hidden values in the granules, v_mfma_f32_16x16x4_f32 (the encoder); its h1-part weights are 128 KiB as
 // f32: two of the eight (k-block, gate) pieces stay in registers, six live in LDS (96 KiB)
-template <bool EXACT>
+// PLANES (f32-class only): x and out_elu are [512 hi | 512 lo] bf16 plane rows (PT_BF16X2, encodec_x2.hip) instead of f32
+template <bool EXACT, bool PLANES = false>
 __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(const LstmPersist8f p) {
   __shared__ float red[L8F_WAVES * 8 * 4 * 32];                       // [wave][layer * 4 + gate][r][lane & 31]: 32 KiB
   __shared__ __attribute__((aligned(16))) char wlds[L8F_WAVES * (EXACT ? 6 * 2048 : 12 * 1024)];   // h1-part weights: lo fragments [wave][k][gate][lane] x 16 B / EXACT: six f32 pieces x 32 B
@@ -1192,7 +1223,15 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
     }
     float xskip = 0.f;
     const int64_t oi1 = ((int64_t)bglob * p.T + (s - 1)) * LP_H + L8_UNITS * u + jj;
-    if (gater && layer == 1 && l1 && bvalid) xskip = p.x[oi1];
+    const int64_t oi1p = ((int64_t)bglob * p.T + (s - 1)) * (2 * LP_H) + L8_UNITS * u + jj;      // PLANES: hi element of the row
+    if (gater && layer == 1 && l1 && bvalid) {
+      if constexpr (PLANES) {
+        const bf16_t* xp = reinterpret_cast<const bf16_t*>(p.x);
+        xskip = bf16_bits_to_f32(xp[oi1p].bits) + bf16_bits_to_f32(xp[oi1p + LP_H].bits);
+      } else {
+        xskip = p.x[oi1];
+      }
+    }
 
     f32x4_t acc[8];                                         // [layer * 4 + gate]: D[row = batch][col = unit]
 #pragma unroll
@@ -1334,7 +1373,14 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
     }
     if (active && layer == 1 && bvalid) {
       const float v = hn + xskip;
-      p.out_elu[oi1] = v < 0.f ? (expf(v) - 1.f) : v;
+      const float e = v < 0.f ? (expf(v) - 1.f) : v;
+      if constexpr (PLANES) {
+        bf16_t* op = reinterpret_cast<bf16_t*>(p.out_elu);
+        const uint16_t eh = f32_to_bf16_bits(e);
+        op[oi1p].bits = eh; op[oi1p + LP_H].bits = f32_to_bf16_bits(e - bf16_bits_to_f32(eh));
+      } else {
+        p.out_elu[oi1] = e;
+      }
     }
   }
 }
@@ -1815,7 +1861,8 @@ extern "C" int pt_rvq_decode(const int64_t* codes, const void* codebooks, void* 
   if (!codes || !pt_aligned16(codebooks) || !pt_aligned16(out)) return PT_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = (B * T * (dim / 4) + 255) / 256; if (blocks > 4096) blocks = 4096;
-  if (dtype == PT_F32) hipLaunchKernelGGL((rvq_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, codes, (const float*)codebooks, (float*)out, B, (int)n_q, T, (int)bins, (int)dim);
+  if (dtype == PT_BF16X2) hipLaunchKernelGGL(rvq_x2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, (const float*)codebooks, (bf16_t*)out, B, (int)n_q, T, (int)bins, (int)dim);
+  else if (dtype == PT_F32) hipLaunchKernelGGL((rvq_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, codes, (const float*)codebooks, (float*)out, B, (int)n_q, T, (int)bins, (int)dim);
   else if (dtype == PT_BF16) hipLaunchKernelGGL((rvq_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, codes, (const bf16_t*)codebooks, (bf16_t*)out, B, (int)n_q, T, (int)bins, (int)dim);
   else return PT_ERR_DTYPE;
   PT_LAUNCH_CHECK();
@@ -1862,7 +1909,15 @@ extern "C" int pt_rowconv(const pt_rowconv_desc* d, int dtype, pt_stream stream)
 
 extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
-  if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
+  if (dtype != PT_F32 && dtype != PT_BF16 && dtype != PT_BF16X2) return PT_ERR_DTYPE;
+  // PT_BF16X2: the f32-class persistent form with x / out_elu as bf16 plane rows (xg0, weights, scratch as for PT_F32); there is
+  // no per-step form of it: where the persistent form does not apply the call is refused with PT_ERR_SHAPE and the caller
+  // converts the planes and takes the PT_F32 path
+  const bool planes = dtype == PT_BF16X2;
+  if (planes) {
+    if (d->exact_f32 || d->per_step) return PT_ERR_SHAPE;
+    dtype = PT_F32;
+  }
   if (d->B <= 0 || d->T <= 0 || d->H <= 0 || d->H % 256 != 0 || d->B > 16 * 65535) return PT_ERR_SHAPE;
   if (!d->x || !d->xg0 || !d->whh0 || !d->wcat1 || !d->bias1 || !d->h0_seq || !d->h1_seq || !d->c0 || !d->c1 || !d->out_elu) return PT_ERR_ARG;
   const void* ptrs[] = {d->x, d->xg0, d->whh0, d->wcat1, d->h0_seq, d->h1_seq, d->out_elu};
@@ -1924,7 +1979,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   const int persist3 = pt_env_int("PT_LSTM_PERSIST_F32", 1);
   const int rows8f = pt_env_int("PT_LSTM_F32_ROWS8", 1);              // read per call: tests compare the forms
   const int64_t ws_need8f = 512 + 2ll * 2 * 64 * 256 * 16;
-  if (persist && (d->exact_f32 ? pt_env_int("PT_LSTM_PERSIST_EXACT", 1) : persist3) && rows8f && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
+  if (persist && (d->exact_f32 ? pt_env_int("PT_LSTM_PERSIST_EXACT", 1) : persist3) && (rows8f || planes) && max_clusters8 >= 1 && dtype == PT_F32 && d->H == LP_H && d->B * d->T * d->H * 4 >= ws_need8f) {
     const char* e_spin = getenv("PT_LSTM_DEBUG_SPIN"); const char* e_fault = getenv("PT_LSTM_DEBUG_FAULT_SLICE");
     const int rows_per_launch = L8_ROWS * max_clusters8;
     PersistTurn turn(device, s);
@@ -1946,11 +2001,13 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
       if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
       if (d->exact_f32) hipLaunchKernelGGL((lstm2_persist8f_kernel<true>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
+      else if (planes) hipLaunchKernelGGL((lstm2_persist8f_kernel<false, true>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
       else hipLaunchKernelGGL((lstm2_persist8f_kernel<false>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
       PT_LAUNCH_CHECK();
     }
     return PT_OK;
   }
+  if (planes) return PT_ERR_SHAPE;
   // ... else 16-row clusters x 64 workgroups, exchange through memory
   const int64_t ws_need3 = 256 + 2ll * 2 * 64 * 256 * 16;
   // exact_f32: the same kernel on the exact f32 MFMA (PT_LSTM_PERSIST_EXACT=0: the per-step kernels)
@@ -1989,8 +2046,13 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
   return PT_OK;
 }
 
+int pt_x2_encodec_res(const pt_encodec_stage_desc* d, hipStream_t s);       // encodec_x2.hip
+int pt_x2_encodec_stage(const pt_encodec_stage_desc* d, hipStream_t s);
+int pt_x2_encodec_tail(const pt_encodec_tail_desc* d, hipStream_t s);
+
 extern "C" int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
+  if (dtype == PT_BF16X2) return pt_x2_encodec_tail(d, (hipStream_t)stream);
   if (dtype != PT_BF16) return PT_ERR_DTYPE;
   if (d->B <= 0 || d->n < 8 || d->cin != TL_CIN || d->cout != TL_C || d->r != 2 || d->B * d->n >= (1ll << 31)) return PT_ERR_SHAPE;
   if (!d->x || !d->wt || !d->bt || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->wfin || !d->bfin || !d->wav) return PT_ERR_ARG;
@@ -2010,6 +2072,7 @@ extern "C" int pt_encodec_tail(const pt_encodec_tail_desc* d, int dtype, pt_stre
 
 extern "C" int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
+  if (dtype == PT_BF16X2) return pt_x2_encodec_stage(d, (hipStream_t)stream);
   if (dtype != PT_BF16) return PT_ERR_DTYPE;
   if (d->B <= 0 || d->n < 4 || d->cin != S2_CIN || d->cout != S2_C || d->r != 4 || d->B * d->n >= (1ll << 29)) return PT_ERR_SHAPE;
   if (!d->x || !d->wt || !d->bt || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->y) return PT_ERR_ARG;
@@ -2029,6 +2092,7 @@ extern "C" int pt_encodec_stage(const pt_encodec_stage_desc* d, int dtype, pt_st
 
 extern "C" int pt_encodec_res(const pt_encodec_stage_desc* d, int dtype, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
+  if (dtype == PT_BF16X2) return pt_x2_encodec_res(d, (hipStream_t)stream);
   if (dtype != PT_BF16) return PT_ERR_DTYPE;
   if (d->B <= 0 || d->n < 3 || d->cin != R1_C || d->cout != R1_C || d->r != 1 || d->B * d->n >= (1ll << 30)) return PT_ERR_SHAPE;
   if (!d->x || !d->w3 || !d->b3 || !d->wf || !d->bf || !d->y) return PT_ERR_ARG;

@@ -43,6 +43,11 @@ struct VOp {
   int64_t step;                // bytes per k-tile inside a segment
   int edge_slow;               // also recompute at positions 1 and seg_kt-1 of a segment (conv rows at batch-item edges)
   int64_t rows, cols;   // logical extent of the virtual matrix
+  // PT_BF16X2 (split storage: a row of C f32-class elements is [C hi | C lo] bf16): the reduction runs over THREE copies of the
+  // logical K columns -- krep = K, cols = 3 K -- and copy s reads plane (pmap >> s) & 1 of the row: activations {hi, hi, lo},
+  // weights {hi, lo, hi}, so that a plain bf16 GEMM over 3 K sums a_hi w_hi + a_hi w_lo + a_lo w_hi (mma.h: the bf16 x 3 product)
+  // with no conversion in its loop.  plane1 / plane2 = element offset of the lo plane in rows of p / p2.  krep = 0: plain storage.
+  int krep, plane1, plane2, pmap;      // (32-bit: eight GemmParams must fit the 4 KiB kernel-argument segment of pt_wgrad_group)
 };
 
 struct GemmParams {
@@ -62,6 +67,9 @@ struct GemmParams {
   const float* scale_a; const float* scale_b;   // pt_gemm_fp8: device-resident dequantisation factors of the two operands
   int nt_store;                // epilogue rows as non-temporal stores (store_out)
   int x3;                      // f32 forward GEMMs: bf16 x 3 products (mma.h) instead of the exact f32 MFMA
+  int planes_c, planes_c2;     // PT_BF16X2 outputs: P > 0 = C / C2 rows are [hi | lo] planes in blocks of P logical columns: column n
+                               // sits at (n / P) 2 P + n % P, its lo part P elements further (P = N: one block; P = cout for a
+                               // transposed conv whose N = r cout columns are r output rows of cout channels each)
 };
 struct f8_t { uint8_t bits; };   // one fp8 operand element (e4m3 or e5m2): addressing only
 
@@ -104,10 +112,16 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
   const char* zero = reinterpret_cast<const char*>(pt_zero_page);
   if (row >= op.rows || col >= op.cols) return zero;
   const T* ptr;
+  int64_t plane = 0;                         // PT_BF16X2: 1 = this copy of the K columns reads the lo plane
+  if (KC != 2 && op.krep > 0) {
+    const int sidx = col >= 2 * (int64_t)op.krep ? 2 : (col >= op.krep ? 1 : 0);
+    col -= (int64_t)sidx * op.krep;
+    plane = (op.pmap >> sidx) & 1;
+  }
   if (KC == 0) {
     ptr = (op.kind == PT_V_PLAIN || col < op.c_split)
-              ? reinterpret_cast<const T*>(op.p) + row * op.ld + col
-              : reinterpret_cast<const T*>(op.p2) + row * op.ld2 + (col - op.c_split);
+              ? reinterpret_cast<const T*>(op.p) + row * op.ld + col + plane * (int64_t)op.plane1
+              : reinterpret_cast<const T*>(op.p2) + row * op.ld2 + (col - op.c_split) + plane * (int64_t)op.plane2;
   } else if (KC == 1) {
     int tap, ci, b, n;
     divmod((int)col, op.cin, op.cin_shift, tap, ci);
@@ -124,7 +138,7 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
       default: /* PT_MAP_BACK */ ns = n - tap; ok = ns >= 0; break;
     }
     if (!ok) return zero;
-    ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)b * op.n_in + ns) * op.ld + ci;
+    ptr = reinterpret_cast<const T*>(op.p) + ((int64_t)b * op.n_in + ns) * op.ld + ci + plane * op.plane1;
   } else {  // PT_V_WFLIP: row = tap*cout + co
     int tap, co;
     divmod((int)row, op.cin, op.cin_shift, tap, co);
@@ -282,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
     // ran at instruction-fetch speed -- 11 us per 256 x 256 tile even with the global stores compiled out (tools/gemm_probe.py
     // 0 9 6), 40 % of a K = 512 GEMM.  The plain case (one output, no activation: most launches) therefore has its own compact
     // body; ELU gets a copy; the GEGLU / two-output variants share the general body below.
-    if (p.act <= 1 && !p.C2) {
+    if (p.act <= 1 && !p.C2 && p.planes_c == 0) {
       // (per-row-block scratch: sc = scratch0 + i * scr_stride)
       bf16_t* Cb0 = reinterpret_cast<bf16_t*>(p.C) + (mbase + rd_row) * p.ldc + nbase + 8 * rd_c;
       const int64_t step8 = 8 * p.ldc;
@@ -438,7 +452,7 @@ if (p.act == 3) {
       }
       return;
     }
-    // two outputs (C, C2) with their own activations (Encodec decoder: raw + ELU copy)
+    // two outputs (C, C2) with their own activations (Encodec decoder: raw + ELU copy); PT_BF16X2: each output as [hi | lo] planes
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       float v[4][4];
@@ -448,23 +462,32 @@ if (p.act == 3) {
         for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
       for (int op = 0; op < (p.C2 ? 2 : 1); ++op) {
         const int act = op == 0 ? p.act : p.act2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float w[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
-          u32x2_t o;
-          o[0] = pack_bf16x2(w[0], w[1]);
-          o[1] = pack_bf16x2(w[2], w[3]);
-          *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
-        }
-        bf16_t* Cb = reinterpret_cast<bf16_t*>(op == 0 ? p.C : p.C2) + (mbase + 16 * i) * (op == 0 ? p.ldc : p.ldc2) + nbase + 8 * rd_c;
+        const int64_t plane_off = op == 0 ? p.planes_c : p.planes_c2;
         const int64_t ld = op == 0 ? p.ldc : p.ldc2;
+        for (int pl = 0; pl < (plane_off > 0 ? 2 : 1); ++pl) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int r = 8 * it + rd_row;
-          const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
-          store_out(reinterpret_cast<u32x4_t*>(Cb + r * ld), ov, p.nt_store);
+          for (int j = 0; j < 4; ++j) {
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
+            u32x2_t o;
+            o[0] = pack_bf16x2(w[0], w[1]);
+            o[1] = pack_bf16x2(w[2], w[3]);
+            if (pl == 1) {                                     // lo plane: what the hi plane's rounding left over
+              o[0] = pack_bf16x2(w[0] - __uint_as_float(o[0] << 16), w[1] - __uint_as_float(o[0] & 0xffff0000u));
+              o[1] = pack_bf16x2(w[2] - __uint_as_float(o[1] << 16), w[3] - __uint_as_float(o[1] & 0xffff0000u));
+            }
+            *reinterpret_cast<u32x2_t*>(scratch + wr_off + (((2 * j + (g >> 1)) ^ (li & 7)) << 4)) = o;
+          }
+          const int64_t ccol = nbase + 8 * rd_c;
+          bf16_t* Cb = reinterpret_cast<bf16_t*>(op == 0 ? p.C : p.C2) + (mbase + 16 * i) * ld +
+                       (plane_off > 0 ? (ccol / plane_off) * 2 * plane_off + ccol % plane_off + pl * plane_off : ccol);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = 8 * it + rd_row;
+            const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((rd_c ^ (r & 7)) << 4));
+            store_out(reinterpret_cast<u32x4_t*>(Cb + r * ld), ov, p.nt_store);
+          }
         }
       }
     }
@@ -510,31 +533,38 @@ if (p.act == 3) {
       const int64_t ld = op == 0 ? p.ldc : p.ldc2;
       const int act = op == 0 ? p.act : p.act2;
       if (!out32) {
+        const int64_t plane_off = op == 0 ? p.planes_c : p.planes_c2;          // PT_BF16X2: [hi | lo] planes
+        for (int pl = 0; pl < (plane_off > 0 ? 2 : 1); ++pl) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float w[4];
+          for (int j = 0; j < 4; ++j) {
+            float w[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
-          u32x2_t o;
-          o[0] = pack_bf16x2(w[0], w[1]);
-          o[1] = pack_bf16x2(w[2], w[3]);
-          const int chunk = 2 * j + (g >> 1);
-          *reinterpret_cast<u32x2_t*>(scratch + li * 128 + ((chunk ^ (li & 7)) << 4) + ((g & 1) << 3)) = o;
-        }
+            for (int r = 0; r < 4; ++r) w[r] = (act == 1 && v[j][r] < 0.f) ? (__expf(v[j][r]) - 1.f) : v[j][r];
+            u32x2_t o;
+            o[0] = pack_bf16x2(w[0], w[1]);
+            o[1] = pack_bf16x2(w[2], w[3]);
+            if (pl == 1) {
+              o[0] = pack_bf16x2(w[0] - __uint_as_float(o[0] << 16), w[1] - __uint_as_float(o[0] & 0xffff0000u));
+              o[1] = pack_bf16x2(w[2] - __uint_as_float(o[1] << 16), w[3] - __uint_as_float(o[1] & 0xffff0000u));
+            }
+            const int chunk = 2 * j + (g >> 1);
+            *reinterpret_cast<u32x2_t*>(scratch + li * 128 + ((chunk ^ (li & 7)) << 4) + ((g & 1) << 3)) = o;
+          }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int r = 8 * it + (lane >> 3), c = lane & 7;
-          const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
-          const int64_t mm = mrow0 + 16 * i + r, nn = n0 + wn * 64 + 8 * c;
-          if (mm < p.M && nn < p.N) {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + mm * ld + nn;
-            if (nn + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
-              *reinterpret_cast<u32x4_t*>(dst) = val;
-            } else {
-              for (int e = 0; e < 8 && nn + e < p.N; ++e) {
-                const uint32_t wv = val[e >> 1];
-                bf16_t h; h.bits = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
-                dst[e] = h;
+          for (int it = 0; it < 2; ++it) {
+            const int r = 8 * it + (lane >> 3), c = lane & 7;
+            const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
+            const int64_t mm = mrow0 + 16 * i + r, nn = n0 + wn * 64 + 8 * c;
+            if (mm < p.M && nn < p.N) {
+              bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + mm * ld + (plane_off > 0 ? (nn / plane_off) * 2 * plane_off + nn % plane_off + pl * plane_off : nn);
+              if (nn + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                *reinterpret_cast<u32x4_t*>(dst) = val;
+              } else {
+                for (int e = 0; e < 8 && nn + e < p.N; ++e) {
+                  const uint32_t wv = val[e >> 1];
+                  bf16_t h; h.bits = (uint16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+                  dst[e] = h;
+                }
               }
             }
           }
@@ -1218,8 +1248,17 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const FoldGroup g) {
   }
 }
 
-VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
+// x2_map: 0 = plain storage; else PT_BF16X2 with this plane map (bit s = plane of copy s of the K columns); cols = 3 K then
+VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es, int x2_map = 0) {
   VOp v;
+  v.krep = 0; v.plane1 = v.plane2 = 0; v.pmap = 0;
+  const int64_t K1 = x2_map ? cols / 3 : cols;                 // logical columns of one copy
+  if (x2_map) {
+    v.krep = (int)K1; v.pmap = x2_map;
+    if (o.kind == PT_V_CONV) v.plane1 = o.cin;
+    else if (o.kind == PT_V_CONCAT) { v.plane1 = (int)o.c_split; v.plane2 = (int)(K1 - o.c_split); }
+    else v.plane1 = (int)K1;
+  }
   v.p = reinterpret_cast<const char*>(o.p); v.p2 = reinterpret_cast<const char*>(o.p2);
   v.ld = o.ld; v.ld2 = o.ld2; v.c_split = o.c_split;
   v.kind = o.kind; v.taps = o.taps; v.cin = o.cin > 0 ? o.cin : 1; v.rowmap = o.rowmap; v.stride = o.stride > 0 ? o.stride : 1;
@@ -1235,6 +1274,17 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es) {
     if (o.kind == PT_V_PLAIN) v.seg_kt = 1 << 30;
     else if (o.kind == PT_V_CONCAT) v.seg_kt = (o.c_split % bk == 0) ? (int)(o.c_split / bk) : 1;
     else if (o.kind == PT_V_CONV) v.seg_kt = (v.cin % bk == 0) ? v.cin / bk : 1;
+    if (x2_map) {
+      // a copy boundary (every K1 columns) must fall on a segment boundary: segments are counted from column 0 in units of seg_kt
+      // k-tiles, so seg_kt bk has to divide K1 (and, for a concat, c_split: the gcd of the two)
+      if (K1 % bk != 0) v.seg_kt = 1;
+      else if (o.kind == PT_V_PLAIN) v.seg_kt = (int)(K1 / bk);
+      else if (o.kind == PT_V_CONCAT && v.seg_kt > 1) {
+        int64_t a = K1 / bk, b = v.seg_kt;
+        while (b) { const int64_t t = a % b; a = b; b = t; }
+        v.seg_kt = (int)a;
+      }
+    }
   } else {                                      // reduction along rows
     if (o.kind == PT_V_PLAIN) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
     else if (o.kind == PT_V_CONCAT && o.ld == o.ld2) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
@@ -1351,7 +1401,14 @@ int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
 // descriptor checks + conversion shared by pt_gemm and pt_wgrad_group
 static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int operand_es = 0) {
   if (!d) return PT_ERR_ARG;
-  if (dtype != PT_F32 && dtype != PT_BF16) return PT_ERR_DTYPE;
+  if (dtype != PT_F32 && dtype != PT_BF16 && dtype != PT_BF16X2) return PT_ERR_DTYPE;
+  const bool x2 = dtype == PT_BF16X2;
+  if (x2) {       // forward GEMMs of f32-class inference only: K-contiguous operands, store epilogue, bias / ELU, one or two outputs
+    if (operand_es != 0 || d->A.trans || d->B.trans || d->out_kind == PT_OUT_F32_ATOMIC || d->split_k != 1 || d->residual || d->residual2 ||
+        d->row_bias || d->act > 1 || d->B.kind != PT_V_PLAIN || d->A.kind == PT_V_WFLIP || d->K % 8 != 0 || d->N % 8 != 0 || 3 * d->K >= (1ll << 31))
+      return PT_ERR_ARG;
+    if (d->A.kind == PT_V_CONCAT && (d->A.c_split <= 0 || d->A.c_split >= d->K)) return PT_ERR_ARG;
+  }
   const int oes_t = dtype == PT_F32 ? 4 : 2;                 // output / residual element size
   const int es = operand_es > 0 ? operand_es : oes_t;        // operand element size (1: fp8 operands, bf16 output)
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return PT_ERR_SHAPE;
@@ -1372,9 +1429,14 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
     if (d->C2 && ((reinterpret_cast<uintptr_t>(d->C2) & 15u) || d->ldc2 % 4 != 0)) return PT_ERR_ALIGN;
   }
   // reduction extent must be whole 16-byte chunks when it lies along operand columns
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
-  p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
+  p.M = d->M; p.N = d->N; p.K = x2 ? 3 * d->K : d->K;
+  if (x2) {       // activations read {hi, hi, lo}, weights {hi, lo, hi} (bit s of the map = plane of copy s)
+    p.A = make_vop(d->A, d->M, 3 * d->K, es, 0x4);
+    p.B = make_vop(d->B, d->N, 3 * d->K, es, 0x2);
+  } else {
+    p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
+    p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
+  }
   if (p.A.step >= (1ll << 32) || p.B.step >= (1ll << 32)) { p.A.seg_kt = 1; p.B.seg_kt = 1; p.A.edge_slow = p.B.edge_slow = 0; }   // absurd strides: always recompute
   p.C = reinterpret_cast<char*>(d->C); p.ldc = d->ldc;
   p.out_kind = d->out_kind; p.split_k = d->split_k;
@@ -1392,6 +1454,10 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
   p.scale_a = p.scale_b = nullptr;
   { static const int nt = pt_env_int("PT_GEMM_NT", 0); p.nt_store = nt; }
   p.x3 = (dtype == PT_F32 && d->f32_x3) ? 1 : 0;
+  if (x2 && (d->x2_block < 0 || (d->x2_block > 0 && (d->x2_block % 8 != 0 || d->N % d->x2_block != 0)))) return PT_ERR_ARG;
+  const int64_t pblock = d->x2_block > 0 ? d->x2_block : d->N;
+  p.planes_c = (x2 && d->out_kind == PT_OUT_T) ? (int)pblock : 0; p.planes_c2 = (x2 && d->C2 && d->out_kind == PT_OUT_T) ? (int)pblock : 0;
+  if (x2 && d->out_kind == PT_OUT_T && (d->ldc < 2 * d->N || d->ldc % 8 != 0 || (d->C2 && (d->ldc2 < 2 * d->N || d->ldc2 % 8 != 0)))) return PT_ERR_ARG;
   if (d->act < 0 || d->act > 3 || d->act2 < 0 || d->act2 > 1 || d->geglu_rows < 0) return PT_ERR_ARG;
   if (d->geglu_rows > 0 && (d->out_kind != PT_OUT_F32_ATOMIC || d->M != 2 * d->geglu_rows || d->geglu_rows % 32 != 0)) return PT_ERR_ARG;
   if (d->act >= 2) {
@@ -1412,7 +1478,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   if (st != PT_OK) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);
-  return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);
+  return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);      // PT_BF16 and PT_BF16X2 (a bf16 GEMM over 3 K plane copies)
 }
 
 // fp8 operands (e4m3 weights; e4m3 or e5m2 activations / gradients), bf16 output, f32 accumulation, every epilogue of pt_gemm.

@@ -133,6 +133,18 @@ class _StatusPool:
             return st
 
 
+def planes_from_f32(x):
+    """(rows, C) f32 -> (rows, 2C) bf16 plane rows [hi | lo] (host-side weight preparation; small-input fallbacks)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=1).contiguous()
+
+
+def planes_to_f32(x):
+    C2 = x.shape[1] // 2
+    return x[:, :C2].float() + x[:, C2:].float()
+
+
 def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None, exact_f32=False, per_step=False):
     """Two-layer LSTM + skip + ELU over (B*T, 512) token-major rows; returns (ELU(h1 + x), LstmStatus to check()).
     `status`: a reusable LstmStatus (pinned allocation is slow) that no other call is using.  per_step: the per-step kernels
@@ -156,6 +168,11 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None,
 # f32 decode: products as a bf16 x 3 split on the bf16 MFMA (error ~2^-16 per product; the decode meets the 1e-3 bound with a
 # wide margin) instead of the exact f32 MFMA, which runs at 1/16 of the bf16 rate.  PT_ENCODEC_F32_X3=0: exact f32 everywhere.
 F32_X3 = __import__("os").environ.get("PT_ENCODEC_F32_X3", "1") != "0"
+# ... and activations in SPLIT storage (PT_BF16X2: a row of C values = [C hi | C lo] bf16 planes, split once by the producer):
+# every GEMM is then a plain bf16 GEMM over 3 K with no conversion in its loop, and the 3 kHz -> 24 kHz end runs as the f32-class
+# fused stage kernels (csrc/encodec_x2.hip).  PT_ENCODEC_F32_PLANES=0: f32 activations, hi / lo split inside the product loops
+# (round 3's path; kept for comparison).
+F32_PLANES = __import__("os").environ.get("PT_ENCODEC_F32_PLANES", "1") != "0"
 FUSED_TAIL = __import__("os").environ.get("PT_ENCODEC_FUSED_TAIL", "1") != "0"
 FUSED_STAGES = __import__("os").environ.get("PT_ENCODEC_FUSED_STAGES", "1") != "0"
 
@@ -169,6 +186,7 @@ class EncodecDecoder:
             raise KeyError(f"missing decoder weights: {missing[:4]}...")
         self.device, self.dtype, self.pt = torch.device(device), dtype, ops._DT[dtype]
         self.x3 = F32_X3 and dtype == torch.float32
+        self.x2 = self.x3 and F32_PLANES
         W = {k: v.detach().float().cpu() for k, v in weights.items()}
         d = lambda t: t.to(self.device, dtype).contiguous()
         f = lambda t: t.to(self.device, torch.float32).contiguous()
@@ -196,6 +214,17 @@ class EncodecDecoder:
                 wf=d(_pad_cols(fused, 32) if small else fused), bf=f(W[f"res{i}.c1.b"] + W[f"res{i}.sc.b"])))
             Cc = cout
         self.wfin, self.bfin = d(_pad_cols(_conv_mat(W["final.w"]), 32)), f(W["final.b"])
+        if self.x2:
+            # split storage: GEMM weights as plane rows [K hi | K lo] (the B operand of a PT_BF16X2 pt_gemm), the fused stage
+            # kernels take the f32 matrices built above and split them per workgroup
+            pl = lambda t: planes_from_f32(t.float().cpu()).to(self.device)
+            self.w0_x2, self.w_ih0_x2 = pl(_conv_mat(W["conv0.w"])), pl(W["lstm.w_ih0"])
+            for i, st in enumerate(self.stages):
+                wt = W[f"up{i}.w"]
+                cin, cout, r = st["cin"], st["cout"], st["r"]
+                st["wt_x2"] = pl(wt.view(cin, cout, 2, r).permute(3, 1, 2, 0).reshape(r * cout, 2 * cin))
+                st["w3_x2"] = pl(_conv_mat(W[f"res{i}.c3.w"]))
+                st["wf_x2"] = pl(torch.cat([W[f"res{i}.c1.w"][:, :, 0], W[f"res{i}.sc.w"][:, :, 0]], dim=1))
 
     # -- helpers --------------------------------------------------------------------------------------------------
     def _lstm_status(self):
@@ -234,6 +263,90 @@ class EncodecDecoder:
             lstm_status.check()
         return wav
 
+    def _decode_x2(self, codes, per_step):
+        """The f32-class decode on split storage (PT_BF16X2): every activation between launches is a bf16 plane row [C hi | C lo]."""
+        B, n_q, T = codes.shape
+        M, X2, bf = B * T, L.PT_BF16X2, torch.bfloat16
+        e0 = self._empty(M, 256, bf)
+        check(lib.pt_rvq_decode(codes.data_ptr(), self.codebooks.data_ptr(), e0.data_ptr(), B, n_q, T, 1024, 128, X2, ops._stream()), "pt_rvq_decode")
+        y0 = self._empty(M, 1024, bf)
+        ops.gemm(M, 512, 7 * 128, ops.conv(e0, 128, T, T, L.PT_MAP_CAUSAL_REFLECT, taps=7), ops.plain(self.w0_x2), y0, X2, ldc=1024, bias=self.b0)
+        xg0 = self._empty(M, 2048, torch.float32)
+        ops.gemm(M, 2048, 512, ops.plain(y0), ops.plain(self.w_ih0_x2), xg0, X2, out_kind=L.PT_OUT_F32, bias=self.bias0)
+        # the recurrence: x / out as plane rows; where the persistent f32-class form does not apply (few rows, the per-step retry)
+        # the planes are converted and the PT_F32 call is made instead
+        st = self._lstm_status()
+        ze = self._empty(M, 1024, bf)
+        done = False
+        if not per_step:
+            h0 = torch.empty(M, 512, dtype=torch.float32, device=self.device)
+            ld = L.pt_lstm2_desc()
+            ld.B, ld.T, ld.H = B, T, 512
+            ld.x, ld.xg0, ld.whh0, ld.wcat1, ld.bias1 = y0.data_ptr(), xg0.data_ptr(), self.w_hh0.data_ptr(), self.wcat1.data_ptr(), self.bias1.data_ptr()
+            ld.h0_seq, ld.h1_seq, ld.c0, ld.c1, ld.out_elu = h0.data_ptr(), h0.data_ptr(), h0.data_ptr(), h0.data_ptr(), ze.data_ptr()
+            ld.status = st.ptr()
+            rc = lib.pt_lstm2_forward(C.byref(ld), X2, ops._stream())
+            if rc == 0:
+                st.fetch()
+                done = True
+            elif rc != -1:                       # PT_ERR_SHAPE = "this form does not apply here"; anything else is an error
+                check(rc, "pt_lstm2_forward")
+        if not done:
+            zf, st = run_lstm2(B, T, planes_to_f32(y0), xg0, self.w_hh0, self.wcat1, self.bias1, L.PT_F32, self.device, torch.float32, st,
+                               per_step=per_step)
+            ze = planes_from_f32(zf)
+        xe, n = ze, T
+        for si, sg in enumerate(self.stages):
+            r, cin, cout = sg["r"], sg["cin"], sg["cout"]
+            Min, Mout, n_out = B * n, B * n * r, n * r
+            if (r, cin, cout) == (2, 64, 32):
+                wav = torch.empty(B * n_out, 1, dtype=torch.float32, device=self.device)
+                td = L.pt_encodec_tail_desc()
+                td.B, td.n, td.cin, td.cout, td.r = B, n, cin, cout, r
+                td.x, td.ldx = xe.data_ptr(), xe.stride(0)
+                td.wt, td.bt, td.w3, td.b3 = sg["wt"].data_ptr(), sg["bt"].data_ptr(), sg["w3"].data_ptr(), sg["b3"].data_ptr()
+                td.wf, td.bf, td.wfin, td.bfin = sg["wf"].data_ptr(), sg["bf"].data_ptr(), self.wfin.data_ptr(), self.bfin.data_ptr()
+                td.wav = wav.data_ptr()
+                check(lib.pt_encodec_tail(C.byref(td), X2, ops._stream()), "pt_encodec_tail")
+                return wav.view(B, 1, n_out), st
+            if (r, cin, cout) == (4, 128, 64):
+                oute = self._empty(Mout, 2 * cout, bf)
+                sd = L.pt_encodec_stage_desc()
+                sd.B, sd.n, sd.cin, sd.cout, sd.r = B, n, cin, cout, r
+                sd.x, sd.ldx = xe.data_ptr(), xe.stride(0)
+                sd.wt, sd.bt, sd.w3, sd.b3 = sg["wt"].data_ptr(), sg["bt"].data_ptr(), sg["w3"].data_ptr(), sg["b3"].data_ptr()
+                sd.wf, sd.bf, sd.y, sd.ldy = sg["wf"].data_ptr(), sg["bf"].data_ptr(), oute.data_ptr(), oute.stride(0)
+                check(lib.pt_encodec_stage(C.byref(sd), X2, ops._stream()), "pt_encodec_stage")
+                xe, n = oute, n_out
+                continue
+            # transposed conv as a GEMM whose N = r cout columns are the r new rows: plane blocks of cout columns
+            x1 = self._empty(Min, 2 * r * cout, bf)
+            A = ops.conv(xe, cin, n, n, L.PT_MAP_BACK, taps=2)
+            if cout == 128:                      # stage 1: raw x1 only, then the fused residual block
+                ops.gemm(Min, r * cout, 2 * cin, A, ops.plain(sg["wt_x2"]), x1, X2, ldc=2 * r * cout, bias=sg["bt"], x2_block=cout)
+                oute = self._empty(Mout, 2 * cout, bf)
+                sd = L.pt_encodec_stage_desc()
+                sd.B, sd.n, sd.cin, sd.cout, sd.r = B, n_out, cout, cout, 1
+                sd.x, sd.ldx = x1.data_ptr(), 2 * cout
+                sd.w3, sd.b3, sd.wf, sd.bf = sg["w3"].data_ptr(), sg["b3"].data_ptr(), sg["wf"].data_ptr(), sg["bf"].data_ptr()
+                sd.y, sd.ldy = oute.data_ptr(), oute.stride(0)
+                check(lib.pt_encodec_res(C.byref(sd), X2, ops._stream()), "pt_encodec_res")
+                xe, n = oute, n_out
+                continue
+            # stage 0 (512 -> 256, r = 8): three GEMMs -- its residual block's weights (0.8 MiB as hi / lo) fit no CU
+            x1e = self._empty(Min, 2 * r * cout, bf)
+            ops.gemm(Min, r * cout, 2 * cin, A, ops.plain(sg["wt_x2"]), x1, X2, ldc=2 * r * cout, bias=sg["bt"], x2_block=cout,
+                     out2=x1e, ldc2=2 * r * cout, act2=1)
+            x1v, x1ev = x1.view(Mout, 2 * cout), x1e.view(Mout, 2 * cout)
+            c3e = self._empty(Mout, cout, bf)            # cout / 2 channels as planes
+            ops.gemm(Mout, cout // 2, 3 * cout, ops.conv(x1ev, cout, n_out, n_out, L.PT_MAP_CAUSAL_REFLECT, taps=3), ops.plain(sg["w3_x2"]),
+                     c3e, X2, ldc=cout, bias=sg["b3"], act=1)
+            oute = self._empty(Mout, 2 * cout, bf)
+            cc = ops.concat(c3e, x1v); cc.c_split = cout // 2
+            ops.gemm(Mout, cout, cout // 2 + cout, cc, ops.plain(sg["wf_x2"]), oute, X2, ldc=2 * cout, bias=sg["bf"], act=1)
+            xe, n = oute, n_out
+        raise RuntimeError("decoder stages do not end in the (2, 64, 32) tail")
+
     def _decode(self, codes, per_step=False):
         if codes.dim() != 3:
             raise BaseException("The encoded_frames must have the shape of [B, N_q, T]")
@@ -243,6 +356,8 @@ class EncodecDecoder:
         B, n_q, T = codes.shape
         if T < 7:
             raise ValueError("the causal reflect padding of the k=7 convs needs at least 7 frames")
+        if self.x2 and [(s["r"], s["cin"], s["cout"]) for s in self.stages] == [(8, 512, 256), (5, 256, 128), (4, 128, 64), (2, 64, 32)]:
+            return self._decode_x2(codes, per_step)
         pt, M = self.pt, B * T
         e0 = self._empty(M, 128)
         check(lib.pt_rvq_decode(codes.data_ptr(), self.codebooks.data_ptr(), e0.data_ptr(), B, n_q, T, 1024, 128, pt,

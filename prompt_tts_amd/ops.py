@@ -67,9 +67,10 @@ def wflip(w3, cout, cin_pad, trans=True):
 
 def gemm(M, N, K, A, B, out, dtype, ldc=None, out_kind=L.PT_OUT_T, split_k=1, bias=None, row_bias=None,
          row_bias_rows=0, row_bias_ld=0, residual=None, ldr=0, residual2=None, ldr2=0, conv_wgrad_cin=0, conv_wgrad_cin_store=0, alpha=1.0,
-         act=0, out2=None, ldc2=0, act2=0, arow_sum=None, arow_n=0, arow_rep=1, arow_stride=0, x3=False):
+         act=0, out2=None, ldc2=0, act2=0, arow_sum=None, arow_n=0, arow_rep=1, arow_stride=0, x3=False, x2_block=0):
     d = L.pt_gemm_desc()
     d.f32_x3 = int(x3)             # f32 only: bf16 x 3 products instead of the exact f32 MFMA (inference at fp32 tolerance)
+    d.x2_block = x2_block          # PT_BF16X2 only: plane blocking of the output columns (0 = N)
     d.M, d.N, d.K = M, N, K
     d.A, d.B = A, B
     d.C = out.data_ptr(); d.ldc = ldc if ldc is not None else N
