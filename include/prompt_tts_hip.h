@@ -374,8 +374,10 @@ int pt_rvq_search(const float* scores, const float* codebook, float* residual, i
  *     status word and the launch's XCD census).  Where the census finds every cluster on one XCD (a 256-CU device: read from the
  *     hardware per launch, never assumed) the exchange stays in that XCD's L2; otherwise it goes through memory (PT_LSTM_FORCE_
  *     REMOTE=1 forces that form).  Every workgroup of a launch must be resident at once; every wait is bounded;
- *   - persistent, f32-class (PT_F32, exact_f32 == 0): bf16 x 3 products, 16-byte granules {hi pair, tag, lo pair, tag} (one tag
- *     per 8-byte half: a torn 16-byte access cannot pass the check); the same
+ *   - persistent, f32-class (PT_F32, exact_f32 == 0): bf16 x 3 products; 8-byte granules of two hidden units, one 32-bit word
+ *     each {hi bf16 | lo bf16 carrying a 2-bit hand-off tag in its lowest mantissa bits} -- a tag in every word, so no access of
+ *     any width can pair a fresh tag with a stale value (PT_LSTM_F32_ROWS8=0's 16-row form: 16-byte granules {hi pair, tag, lo
+ *     pair, tag}, one tag per 8-byte half); the same
  *     8-row x 32-workgroup clusters (eight waves per workgroup, hi / lo weight fragments in registers and LDS), XCD-local where the
  *     census allows; PT_LSTM_F32_ROWS8=0: clusters of 16 rows x 64 workgroups exchanging through memory;
  *   - persistent, exact f32 (PT_F32, exact_f32 != 0): that kernel on v_mfma_f32_16x16x4_f32 with the f32 hidden values themselves

@@ -1115,6 +1115,23 @@ struct LstmPersist8f {
 };
 constexpr int L8F_WAVES = 8;
 
+// f32-class form, COMPACT granules (round 4): 8 bytes = two hidden units, one 32-bit word each: {hi bf16 | lo bf16 with the hand-off
+// tag in its two lowest mantissa bits}.  A granule slot is rewritten every second tick and producers never run more than one tick
+// ahead of their consumers, so a tag only has to tell tick s from tick s - 2 and from the cleared buffer: two bits (values 1 / 2,
+// flipping every second tick), one tag per 32-bit word -- no store or load of any width can show a fresh tag over a stale value.
+// The lo part keeps six mantissa bits: a product's error grows from ~2^-17 to ~2^-15, far inside the decoder's 1e-3 bound, and a
+// workgroup's poll is 32 KiB per tick instead of 64 (the poll was 57 % of the tick: 4.45 -> see DESIGN.md).
+__device__ __forceinline__ unsigned l8c_tag(int tick) { return (unsigned)(((tick >> 1) & 1) + 1); }
+// slot j <- w[16 (j >> 2) + (j & 3)]: the k-order in which the compact granule loads deliver the A operand (as lp_load_w)
+__device__ __forceinline__ void split_bf16x8c(const float* w, Frag<bf16_t>& hi, Frag<bf16_t>& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = w[16 * (j >> 2) + (j & 3)];
+    const __bf16 h = (__bf16)x;
+    hi.v[j] = h; lo.v[j] = (__bf16)(x - (float)h);
+  }
+}
+
 template <int AUX>
 __device__ __forceinline__ void l8f_load(u32x4_t (&v0)[4], u32x4_t (&v1)[4], __amdgpu_buffer_rsrc_t grs, int voff0, int voff1, bool need1) {
 #pragma unroll
@@ -1171,7 +1188,7 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
       const int64_t grow = (int64_t)tl * LP_H + L8_UNITS * u + li;
-      const int k0 = 32 * (2 * wave + k) + 2 * g;
+      const int k0 = 32 * (2 * wave + k) + (EXACT ? 2 : 4) * g;
       if constexpr (EXACT) {
         float t1b[8];
 #pragma unroll
@@ -1190,11 +1207,11 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
           *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){t1b[4], t1b[5], t1b[6], t1b[7]};
         }
       } else {
-        split_bf16x8(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
+        split_bf16x8c(p.whh0 + grow * LP_H + k0, w0h[k][tl], w0l[k][tl]);
         Frag<bf16_t> lo;
-        split_bf16x8(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], lo);
+        split_bf16x8c(p.wcat1 + grow * 2 * LP_H + k0, w1ah[k][tl], lo);
         if (k == 0) w1al[tl] = lo; else *reinterpret_cast<bf16x8_t*>(wl + ((8 + tl) * 64 + lane) * 16) = lo.v;
-        split_bf16x8(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
+        split_bf16x8c(p.wcat1 + grow * 2 * LP_H + LP_H + k0, w1bh[k][tl], lo);
         *reinterpret_cast<bf16x8_t*>(wl + ((k * 4 + tl) * 64 + lane) * 16) = lo.v;
       }
     }
@@ -1209,7 +1226,7 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
     for (int gi = 0; gi < 4; ++gi) bias[gi] = p.bias1[gi * LP_H + L8_UNITS * u + jj];
   }
   float cstate = 0.f;
-  const int gbytes = 2 * 2 * rows * 256 * 16;
+  const int gbytes = 2 * 2 * rows * 256 * (EXACT ? 16 : 8);
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, gbytes, 0x00020000);
   __syncthreads();
 
@@ -1238,23 +1255,48 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
     for (int i = 0; i < 8; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (s >= 1) {
       const int par = (s - 1) & 1;
-      const unsigned want = (unsigned)s;
-      // a k-block = 16 granules = two 128-byte lines of a row; lane (li, g) reads chunk g + 4 (li >> 3) of each line of row li & 7
+      const unsigned want = EXACT ? (unsigned)s : l8c_tag(s - 1);
+      // EXACT: a k-block = 16 granules of 16 bytes = two 128-byte lines of a row; lane (li, g) reads chunk g + 4 (li >> 3) of each
+      // line of row li & 7.  f32-class: 16 compact granules = ONE line; the lane reads chunk g + 4 (li >> 3) = four hidden units
       const int row = L8_ROWS * c + (li & 7), chunk = g + 4 * (li >> 3);
-      const int voff0 = (((par * 2 + 0) * rows + row) * 256 + 32 * wave + chunk) * 16;
-      const int voff1 = (((par * 2 + 1) * rows + row) * 256 + 32 * wave + chunk) * 16;
+      const int voff0 = EXACT ? (((par * 2 + 0) * rows + row) * 256 + 32 * wave + chunk) * 16 : (((par * 2 + 0) * rows + row) * 256 + 32 * wave + 2 * chunk) * 8;
+      const int voff1 = EXACT ? (((par * 2 + 1) * rows + row) * 256 + 32 * wave + chunk) * 16 : (((par * 2 + 1) * rows + row) * 256 + 32 * wave + 2 * chunk) * 8;
       const bool need1 = s >= 2;
-      u32x4_t v0[4], v1[4];                                 // [2 k + line]
+      u32x4_t v0[4], v1[4];                                 // EXACT: [2 k + line]; f32-class: [k], k < 2
       int spin = 0;
       bool aborted = false;
       for (;;) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i] = (u32x4_t){0u, want, 0u, want}; v1[i] = (u32x4_t){0u, want, 0u, want}; }
-        if (local) l8f_load<2>(v0, v1, grs, voff0, voff1, need1);
-        else l8f_load<16>(v0, v1, grs, voff0, voff1, need1);
         bool ok = true;
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ok &= (v0[i][1] == want) & (v0[i][3] == want) & (v1[i][1] == want) & (v1[i][3] == want);
+          for (int i = 0; i < 4; ++i) { v0[i] = (u32x4_t){0u, want, 0u, want}; v1[i] = (u32x4_t){0u, want, 0u, want}; }
+          if (local) l8f_load<2>(v0, v1, grs, voff0, voff1, need1);
+          else l8f_load<16>(v0, v1, grs, voff0, voff1, need1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ok &= (v0[i][1] == want) & (v0[i][3] == want) & (v1[i][1] == want) & (v1[i][3] == want);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { v0[k] = (u32x4_t){want, want, want, want}; v1[k] = (u32x4_t){want, want, want, want}; }
+          if (local) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v0[k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, 2);
+            if (need1) {
+#pragma unroll
+              for (int k = 0; k < 2; ++k) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, 2);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v0[k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff0 + 128 * k, 0, 16);
+            if (need1) {
+#pragma unroll
+              for (int k = 0; k < 2; ++k) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(grs, voff1 + 128 * k, 0, 16);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok &= ((v0[k][e] & 3u) == want) & ((v1[k][e] & 3u) == want);
+        }
         if (__all(ok)) break;
         if (++spin > p.spin_limit || ((spin & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           if (lane == 0) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abort_flag = 1; }
@@ -1288,12 +1330,17 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
       if (!aborted) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          // slots (0,1) own line 0, (2,3) lane li + 8's line 0, (4,5) own line 1, (6,7) lane li + 8's line 1; word 0 = hi pair, 2 = lo pair
+          // a word = one hidden unit {lo' | hi << 16}; the lane's four words = slots 0 .. 3 (units 4 g ..), lane li + 8's four =
+          // slots 4 .. 7 (units 16 + 4 g ..); v_perm pairs the hi halves / the lo halves of two words, the tag bits are masked off
           Frag<bf16_t> a0h, a0l, a1h, a1l;
-          const u32x4_t h0 = {v0[2 * k][0], l8_from_upper(v0[2 * k][0]), v0[2 * k + 1][0], l8_from_upper(v0[2 * k + 1][0])};
-          const u32x4_t o0 = {v0[2 * k][2], l8_from_upper(v0[2 * k][2]), v0[2 * k + 1][2], l8_from_upper(v0[2 * k + 1][2])};
-          const u32x4_t h1 = {v1[2 * k][0], l8_from_upper(v1[2 * k][0]), v1[2 * k + 1][0], l8_from_upper(v1[2 * k + 1][0])};
-          const u32x4_t o1 = {v1[2 * k][2], l8_from_upper(v1[2 * k][2]), v1[2 * k + 1][2], l8_from_upper(v1[2 * k + 1][2])};
+          const unsigned hA0 = __builtin_amdgcn_perm(v0[k][1], v0[k][0], 0x07060302u), hB0 = __builtin_amdgcn_perm(v0[k][3], v0[k][2], 0x07060302u);
+          const unsigned lA0 = __builtin_amdgcn_perm(v0[k][1], v0[k][0], 0x05040100u) & 0xfffcfffcu, lB0 = __builtin_amdgcn_perm(v0[k][3], v0[k][2], 0x05040100u) & 0xfffcfffcu;
+          const unsigned hA1 = __builtin_amdgcn_perm(v1[k][1], v1[k][0], 0x07060302u), hB1 = __builtin_amdgcn_perm(v1[k][3], v1[k][2], 0x07060302u);
+          const unsigned lA1 = __builtin_amdgcn_perm(v1[k][1], v1[k][0], 0x05040100u) & 0xfffcfffcu, lB1 = __builtin_amdgcn_perm(v1[k][3], v1[k][2], 0x05040100u) & 0xfffcfffcu;
+          const u32x4_t h0 = {hA0, hB0, l8_from_upper(hA0), l8_from_upper(hB0)};
+          const u32x4_t o0 = {lA0, lB0, l8_from_upper(lA0), l8_from_upper(lB0)};
+          const u32x4_t h1 = {hA1, hB1, l8_from_upper(hA1), l8_from_upper(hB1)};
+          const u32x4_t o1 = {lA1, lB1, l8_from_upper(lA1), l8_from_upper(lB1)};
           a0h.v = __builtin_bit_cast(bf16x8_t, h0); a0l.v = __builtin_bit_cast(bf16x8_t, o0);
           a1h.v = __builtin_bit_cast(bf16x8_t, h1); a1l.v = __builtin_bit_cast(bf16x8_t, o1);
 #pragma unroll
@@ -1356,19 +1403,32 @@ __global__ __launch_bounds__(64 * L8F_WAVES, 1) void lstm2_persist8f_kernel(cons
       }
     }
     if (gater && s < p.T) {
-      // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {hi pair, tag, lo pair, tag}, by the even lane
-      const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
-      const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
-      const unsigned hi_o = (unsigned)__shfl_down((int)hi, 1, 64), lo_o = (unsigned)__shfl_down((int)lo, 1, 64);
-      const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
-      if ((jj & 1) == 0) {
-        const bool faulty = c * L8_SLICES + u == p.fault_slice;     // test hook; fault_half 1 / 2: only that half's tag is wrong
-        const unsigned tag = (unsigned)(s + 1);
-        const unsigned tag_a = tag + (faulty && p.fault_half != 2 ? 0x40000000u : 0u), tag_b = tag + (faulty && p.fault_half != 1 ? 0x40000000u : 0u);
-        const u32x4_t gran = EXACT ? (u32x4_t){__float_as_uint(hn), tag_a, hn_o, tag_b} : (u32x4_t){hi | (hi_o << 16), tag_a, lo | (lo_o << 16), tag_b};
-        u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
-        if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+      const bool faulty = c * L8_SLICES + u == p.fault_slice;       // test hook; fault_half 1 / 2: only that half's tag is wrong
+      if constexpr (EXACT) {
+        // publish h0_s / h1_{s-1}: units (jj, jj + 1) of a row -> one 16-byte granule {f32, tag, f32, tag}, by the even lane
+        const unsigned hn_o = (unsigned)__shfl_down((int)__float_as_uint(hn), 1, 64);
+        if ((jj & 1) == 0) {
+          const unsigned tag = (unsigned)(s + 1);
+          const unsigned tag_a = tag + (faulty && p.fault_half != 2 ? 0x40000000u : 0u), tag_b = tag + (faulty && p.fault_half != 1 ? 0x40000000u : 0u);
+          const u32x4_t gran = (u32x4_t){__float_as_uint(hn), tag_a, hn_o, tag_b};
+          u32x4_t* dst = p.gx + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b)) * 256 + (L8_UNITS * u + jj) / 2;
+          if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+        }
+      } else {
+        // compact granule: units (jj, jj + 1) -> 8 bytes {word(jj), word(jj + 1)}, word = lo' | hi << 16, tag in bits 0 .. 1
+        const unsigned hi = (unsigned)f32_to_bf16_bits(hn);
+        const unsigned lo = (unsigned)f32_to_bf16_bits(hn - bf16_bits_to_f32((uint16_t)hi));
+        const unsigned tag = l8c_tag(s);
+        const unsigned mine = (hi << 16) | (lo & 0xfffcu);
+        const unsigned other = (unsigned)__shfl_down((int)mine, 1, 64);
+        if ((jj & 1) == 0) {
+          const unsigned tag_a = (faulty && p.fault_half != 2) ? (tag ^ 3u) : tag, tag_b = (faulty && p.fault_half != 1) ? (tag ^ 3u) : tag;
+          const u32x2_t gran = {mine | tag_a, other | tag_b};
+          char* dst = reinterpret_cast<char*>(p.gx) + ((size_t)(((s & 1) * 2 + layer) * rows + L8_ROWS * c + b) * 256 + (L8_UNITS * u + jj) / 2) * 8;
+          if (local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+        }
       }
     }
     if (active && layer == 1 && bvalid) {
@@ -1999,7 +2059,7 @@ extern "C" int pt_lstm2_forward(const pt_lstm2_desc* d, int dtype, pt_stream str
       q.fault_half = pt_env_int("PT_LSTM_DEBUG_FAULT_HALF", 0);
       const bool first = b0 == 0;
       char* clr = reinterpret_cast<char*>(d->h0_seq) + (first ? 0 : 256);
-      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * 16), s) != hipSuccess) return PT_ERR_LAUNCH;
+      if (hipMemsetAsync(clr, 0, (size_t)((first ? 256 : 0) + 256 + 2ll * 2 * q.clusters * L8_ROWS * 256 * (d->exact_f32 ? 16 : 8)), s) != hipSuccess) return PT_ERR_LAUNCH;
       if (d->exact_f32) hipLaunchKernelGGL((lstm2_persist8f_kernel<true>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
       else if (planes) hipLaunchKernelGGL((lstm2_persist8f_kernel<false, true>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
       else hipLaunchKernelGGL((lstm2_persist8f_kernel<false>), dim3((unsigned)(max_clusters8 * L8_SLICES)), dim3(64 * L8F_WAVES), 0, s, q);
