@@ -126,9 +126,10 @@ def test_fused_24khz_tail_equals_the_separate_launches(dev, B, T, monkeypatch):
 
 @pytest.mark.gpu
 def test_decode_at_configs3_size_bf16_vs_f32_and_oracle(dev):
-    """BASELINE configs[3]: 64 prompts x 1024 frames.  bf16 (the bench dtype, persistent LSTM over 1024 recurrent steps) against
-    the f32 parity-mode decoder on all 64 items, and one item against the CPU oracle (f32, T = 1024).  Stated bound for the
-    1024-step bf16 recurrence: 8e-2 of the waveform peak, 2e-2 relative RMS."""
+    """BASELINE configs[3]: 64 prompts x 1024 frames.  The f32-class decoder (the bench's headline path: split storage, fused
+    f32-class stages, persistent LSTM over 1024 recurrent steps) on four full-length items against the CPU oracle at north_star's
+    1e-3; the bf16 decoder against it on all 64 items (stated bound for the 1024-step bf16 recurrence: 8e-2 of the waveform peak,
+    2e-2 relative RMS -- outside north_star's bound, which is why bf16 is not the headline)."""
     from oracle import encodec as oe
     from prompt_tts_amd.encodec import EncodecDecoder
     W = oe.random_weights(6)
@@ -139,9 +140,11 @@ def test_decode_at_configs3_size_bf16_vs_f32_and_oracle(dev):
     peak = float(f32.abs().max())
     assert float((bf - f32).abs().max()) < 8e-2 * peak
     assert float((bf - f32).pow(2).mean().sqrt() / f32.pow(2).mean().sqrt()) < 2e-2
-    want = oe.decode(codes[17:18], W)                                   # CPU oracle, one full-length item
-    assert float((f32[17:18] - want).abs().max()) < 1e-3 * float(want.abs().max())
-    assert float((bf[17:18] - want).abs().max()) < 8e-2 * float(want.abs().max())
+    for item in (0, 17, 40, 63):                                        # CPU oracle, four full-length items (first / last cluster rows too)
+        want = oe.decode(codes[item:item + 1], W)
+        err = float((f32[item:item + 1] - want).abs().max()) / float(want.abs().max())
+        assert err < 1e-3, (item, err)                                  # north_star's bound, at the reference's precision (f32-class path)
+        assert float((bf[item:item + 1] - want).abs().max()) < 8e-2 * float(want.abs().max())
 
 
 @pytest.mark.gpu
