@@ -337,6 +337,36 @@ def test_exact_f32_persistent_lstm_of_the_encoder(dev, B, T, rows16, monkeypatch
 
 
 @pytest.mark.gpu
+def test_hip_encoder_at_generate_code_size(dev):
+    """data_preparation/generate_code.py:96 encodes batches of 32 windows x 12 s (288 000 samples -> 900 frames).  The HIP encoder
+    at exactly that size (two persistent-LSTM launches: 32 rows = 4 clusters... of 8), three of the 32 items against the CPU oracle:
+    embeddings within 1e-3 of the peak, the search bit-exact given its input (codes == f64 search of the device embeddings except
+    at f64 near-ties < 1e-4), end-to-end code agreement >= 97 % (embeddings differ at ~1e-6, only near-ties flip)."""
+    from oracle import encodec as oe
+    from prompt_tts_amd.encodec import EncodecEncoder
+    W = oe.random_encoder_weights(5)
+    B, T = 32, 900
+    wav = torch.randn(B, 1, 320 * T, generator=torch.Generator().manual_seed(96)) * 0.5
+    enc = EncodecEncoder(W, device=dev, dtype=torch.float32)
+    emb, b, t = enc.embeddings(wav.to(dev))
+    assert (b, t) == (B, T)
+    codes = enc.quantize(emb, b, t).cpu()
+    assert codes.shape == (B, 8, T) and codes.dtype == torch.int64 and int(codes.min()) >= 0 and int(codes.max()) < 1024
+    got_all = emb.view(B, T, 128).permute(0, 2, 1).cpu()
+    for item in (0, 13, 31):
+        want = oe.encoder_embeddings(wav[item:item + 1], W)
+        got = got_all[item:item + 1]
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 1e-3, (item, err)
+        ref, gaps = oe.rvq_encode(got, W["codebooks"], torch.float64)
+        bad = codes[item:item + 1] != ref
+        first_bad = bad.int().argmax(dim=1, keepdim=True)
+        any_bad = bad.any(dim=1, keepdim=True)
+        assert bool(((~any_bad) | (gaps.gather(1, first_bad) < 1e-4)).all()), "search disagrees away from a near-tie"
+        assert float((codes[item:item + 1] == oe.encode(wav[item:item + 1], W)).float().mean()) > 0.97
+
+
+@pytest.mark.gpu
 def test_hip_encoder_causal_and_batch_independent(dev):
     """Size-independent properties at a longer length: items are independent; a prefix encodes to the prefix of the codes."""
     from oracle import encodec as oe

@@ -116,3 +116,27 @@ def test_two_ranks_odd_batch_count_end_of_epoch(dev, tmp_path):
     assert extra["global_step"] == 6 and extra["opt_step"] == 4 and len(extra["gen_state"]) == 2
     sd = torch.load(d + "ckpt_2.pt", map_location="cpu")
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_accelerate_launch_entry_point(dev, tmp_path, nproc):
+    """The reference is started as `accelerate launch train.py ...` (README.md:36-42, train.py:25-29); north_star keeps that entry
+    point.  Run it: accelerate's launcher (1 process: its simple launcher; 2 processes: its torch.distributed.run launcher, both
+    ranks on this one GPU over gloo -- PT_TRAIN_BACKEND, as the other two-rank tests) must start train.py, which must train an
+    epoch on synthetic items and write the reference's checkpoint files."""
+    d = str(tmp_path) + os.sep
+    cfg = os.path.join(d, "cfg.json")
+    json.dump(_config(1), open(cfg, "w"))
+    cmd = [sys.executable, "-m", "accelerate.commands.launch", "--num_processes", str(nproc), "--num_machines", "1",
+           "--mixed_precision", "no", "--dynamo_backend", "no"]
+    if nproc > 1:
+        cmd += ["--multi_gpu", "--main_process_ip", "127.0.0.1", "--main_process_port", "29653"]
+    cmd += [os.path.join(ROOT, "train.py"), "--synthetic", "16", "--config_file", cfg, "--log_dir", d, "--ckpt_dir", d,
+            "--batch_size", "4", "--max_seq_length", "64", "--dtype", "bf16"]
+    env = dict(os.environ, PT_TRAIN_BACKEND="gloo" if nproc > 1 else "nccl", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(cmd, cwd=ROOT, timeout=900, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    sd = torch.load(os.path.join(d, "ckpt_1.pt"), map_location="cpu")
+    assert "text_encoder.word_embedding.weight" in sd and os.path.exists(os.path.join(d, "optim_1.pt"))
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
