@@ -210,7 +210,7 @@ def decode_time(dev, dtype, prompts, T, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.float32, cpu=True):
+def decode_bench(dev, prompts=64, T=1024, iters=8, dtype=torch.float32, cpu=True):
     """BASELINE configs[3] second half: Encodec 24 kHz decode of `prompts` x T frames -> generated-audio-seconds/s.
     The headline is the decoder at the REFERENCE's precision (decode_codec.py:12-16 decodes in fp32): f32-class arithmetic (bf16 x 3
     products on split storage, error ~2e-5 of the waveform peak against a bound of 1e-3).  The bf16 decoder is faster but misses
@@ -220,7 +220,9 @@ def decode_bench(dev, prompts=64, T=1024, iters=5, dtype=torch.float32, cpu=True
     from prompt_tts_amd import ops as _ops
     dec = EncodecDecoder(random_decoder_weights(0), device=dev, dtype=dtype)
     codes = torch.randint(0, 1024, (prompts, 8, T), generator=torch.Generator().manual_seed(7)).to(dev)
-    dec.decode(codes); torch.cuda.synchronize()
+    for _ in range(2):                       # the first calls pay for ~10 GB of fresh allocations
+        dec.decode(codes)
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

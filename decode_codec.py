@@ -18,7 +18,9 @@ from prompt_tts_amd.encodec import EncodecDecoder, weights_from_encodec_state_di
 _model = None
 
 
-def load_decoder(weights_path=None, dtype=torch.bfloat16, device="cuda", seed=0, random_weights=False):
+def load_decoder(weights_path=None, dtype=torch.float32, device="cuda", seed=0, random_weights=False):
+    """dtype: torch.float32 (default) = the reference's precision (decode_codec.py:12-16 decodes in fp32): f32-class arithmetic,
+    1e-3-exact against it; torch.bfloat16 = 1.7x faster at ~1e-2 of the waveform peak (a preview mode)."""
     global _model
     if weights_path is not None:
         W = weights_from_encodec_state_dict(torch.load(weights_path, map_location="cpu"))
@@ -70,7 +72,7 @@ def write_wav(path, wav, sample_rate=EncodecDecoder.sample_rate):
     wavfile.write(path, sample_rate, (mono * 32767.0).astype(np.int16))
 
 
-def run_cli(npy_path, weights=None, dtype="bf16", random_weights=False):
+def run_cli(npy_path, weights=None, dtype="f32", random_weights=False):
     """`--npy_path x.npy` -> x.wav (first item of the batch), as the reference's command line does."""
     codes = torch.from_numpy(np.load(npy_path))
     if codes.dim() == 2:                          # a single utterance saved as [N_q, T]
@@ -87,7 +89,8 @@ if __name__ == "__main__":
     cli.add_argument("--npy_path", required=True, help="codec code matrix written by the data preparation")
     cli.add_argument("--weights", default=None, help="encodec state_dict (.pt) in the original package's naming")
     cli.add_argument("--random_weights", action="store_true", help="seeded random decoder (writes noise: plumbing tests only)")
-    cli.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    cli.add_argument("--dtype", default="f32", choices=["bf16", "f32"],
+                     help="f32 (default): the reference's fp32 precision (f32-class arithmetic); bf16: faster, ~1e-2 of the waveform peak")
     ns = cli.parse_args()
     if ns.weights is None and not ns.random_weights:
         cli.error("--weights <encodec state_dict .pt> is required (or --random_weights for a plumbing run)")
