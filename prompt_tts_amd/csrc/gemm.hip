@@ -107,13 +107,16 @@ __device__ __forceinline__ void divmod(int x, int d, int shift, int& q, int& r) 
 // address of the 16-byte chunk V[row][col .. col+EPC) of a virtual matrix, or the zero page
 // KC = kind class, fixed at compile time so that only one addressing scheme's invariants occupy registers:
 // 0 plain / channel-concat, 1 conv gather, 2 flipped conv weights
-template <typename T, int KC>
+// X2 (compile time): the operand may be PT_BF16X2 split storage.  A separate instantiation, not a run-time branch in the common
+// kernels: with the plane fields live in every kernel the register allocation of ALL of them moved (eight-phase forward kernel:
+// 28 -> 74 spilled registers, grouped wgrad 15 -> 30) and the training step lost 5 % (39.96 -> 42.0 ms on one box)
+template <typename T, int KC, bool X2 = false>
 __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t col) {
   const char* zero = reinterpret_cast<const char*>(pt_zero_page);
   if (row >= op.rows || col >= op.cols) return zero;
   const T* ptr;
   int64_t plane = 0;                         // PT_BF16X2: 1 = this copy of the K columns reads the lo plane
-  if (KC != 2 && op.krep > 0) {
+  if (X2 && KC != 2 && op.krep > 0) {
     const int sidx = col >= 2 * (int64_t)op.krep ? 2 : (col >= op.krep ? 1 : 0);
     col -= (int64_t)sidx * op.krep;
     plane = (op.pmap >> sidx) & 1;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void store_out(u32x4_t* dst, const u32x4_t v, int nt)
 
 // ---- epilogue (shared by both kernels): acc[i][j] is the 16x16 tile at rows 16 i, columns 16 j of the wave's
 // (16 MI) x 64 sub-tile whose origin is (m0 + wm * 16 MI, n0 + wn * 64); `scratch` = 2 KiB of wave-private LDS ----------
-template <typename T, bool ATOMIC, int MI, int BM, int BN>
+template <typename T, bool ATOMIC, int MI, int BM, int BN, bool X2 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], const int64_t m0, const int64_t n0,
                                               const int wm, const int wn, const int lane, char* scratch0,
                                               const int scr_stride = 0) {
@@ -296,7 +299,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
     // ran at instruction-fetch speed -- 11 us per 256 x 256 tile even with the global stores compiled out (tools/gemm_probe.py
     // 0 9 6), 40 % of a K = 512 GEMM.  The plain case (one output, no activation: most launches) therefore has its own compact
     // body; ELU gets a copy; the GEGLU / two-output variants share the general body below.
-    if (p.act <= 1 && !p.C2 && p.planes_c == 0) {
+    if (p.act <= 1 && !p.C2 && !(X2 && p.planes_c > 0)) {
       // (per-row-block scratch: sc = scratch0 + i * scr_stride)
       bf16_t* Cb0 = reinterpret_cast<bf16_t*>(p.C) + (mbase + rd_row) * p.ldc + nbase + 8 * rd_c;
       const int64_t step8 = 8 * p.ldc;
@@ -462,9 +465,9 @@ if (p.act == 3) {
         for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
       for (int op = 0; op < (p.C2 ? 2 : 1); ++op) {
         const int act = op == 0 ? p.act : p.act2;
-        const int64_t plane_off = op == 0 ? p.planes_c : p.planes_c2;
+        const int64_t plane_off = X2 ? (op == 0 ? p.planes_c : p.planes_c2) : 0;
         const int64_t ld = op == 0 ? p.ldc : p.ldc2;
-        for (int pl = 0; pl < (plane_off > 0 ? 2 : 1); ++pl) {
+        for (int pl = 0; pl < (X2 && plane_off > 0 ? 2 : 1); ++pl) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float w[4];
@@ -473,7 +476,7 @@ if (p.act == 3) {
             u32x2_t o;
             o[0] = pack_bf16x2(w[0], w[1]);
             o[1] = pack_bf16x2(w[2], w[3]);
-            if (pl == 1) {                                     // lo plane: what the hi plane's rounding left over
+            if (X2 && pl == 1) {                               // lo plane: what the hi plane's rounding left over
               o[0] = pack_bf16x2(w[0] - __uint_as_float(o[0] << 16), w[1] - __uint_as_float(o[0] & 0xffff0000u));
               o[1] = pack_bf16x2(w[2] - __uint_as_float(o[1] << 16), w[3] - __uint_as_float(o[1] & 0xffff0000u));
             }
@@ -481,7 +484,7 @@ if (p.act == 3) {
           }
           const int64_t ccol = nbase + 8 * rd_c;
           bf16_t* Cb = reinterpret_cast<bf16_t*>(op == 0 ? p.C : p.C2) + (mbase + 16 * i) * ld +
-                       (plane_off > 0 ? (ccol / plane_off) * 2 * plane_off + ccol % plane_off + pl * plane_off : ccol);
+                       (X2 && plane_off > 0 ? (ccol / plane_off) * 2 * plane_off + ccol % plane_off + pl * plane_off : ccol);
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int r = 8 * it + rd_row;
@@ -533,8 +536,8 @@ if (p.act == 3) {
       const int64_t ld = op == 0 ? p.ldc : p.ldc2;
       const int act = op == 0 ? p.act : p.act2;
       if (!out32) {
-        const int64_t plane_off = op == 0 ? p.planes_c : p.planes_c2;          // PT_BF16X2: [hi | lo] planes
-        for (int pl = 0; pl < (plane_off > 0 ? 2 : 1); ++pl) {
+        const int64_t plane_off = X2 ? (op == 0 ? p.planes_c : p.planes_c2) : 0;          // PT_BF16X2: [hi | lo] planes
+        for (int pl = 0; pl < (X2 && plane_off > 0 ? 2 : 1); ++pl) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float w[4];
@@ -543,7 +546,7 @@ if (p.act == 3) {
             u32x2_t o;
             o[0] = pack_bf16x2(w[0], w[1]);
             o[1] = pack_bf16x2(w[2], w[3]);
-            if (pl == 1) {
+            if (X2 && pl == 1) {
               o[0] = pack_bf16x2(w[0] - __uint_as_float(o[0] << 16), w[1] - __uint_as_float(o[0] & 0xffff0000u));
               o[1] = pack_bf16x2(w[2] - __uint_as_float(o[1] << 16), w[3] - __uint_as_float(o[1] & 0xffff0000u));
             }
@@ -556,7 +559,7 @@ if (p.act == 3) {
             const u32x4_t val = *reinterpret_cast<const u32x4_t*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
             const int64_t mm = mrow0 + 16 * i + r, nn = n0 + wn * 64 + 8 * c;
             if (mm < p.M && nn < p.N) {
-              bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + mm * ld + (plane_off > 0 ? (nn / plane_off) * 2 * plane_off + nn % plane_off + pl * plane_off : nn);
+              bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + mm * ld + (X2 && plane_off > 0 ? (nn / plane_off) * 2 * plane_off + nn % plane_off + pl * plane_off : nn);
               if (nn + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
                 *reinterpret_cast<u32x4_t*>(dst) = val;
               } else {
@@ -618,7 +621,7 @@ template <int BM_, int BN_> struct TileCfg {
 
 // F8 (T = bf16_t only): fp8 operands as in gemm8p_body -- 128 one-byte elements per k-tile row, the same images and fragment reads,
 // one v_mfma_f32_16x16x128_f8f6f4 per pair of 16-byte fragment reads; 1: activations e4m3, 2: e5m2 (weights always e4m3).
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN, int F8 = 0>
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN, int F8 = 0, bool X2 = false>
 __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_WAVES_PER_SIMD)) void gemm_kernel(const GemmParams p) {
   using Cfg = TileCfg<BM, BN>;
   using TO = typename std::conditional<F8 != 0, f8_t, T>::type;     // operand element (addressing)
@@ -706,15 +709,15 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
 #pragma unroll
       for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
         const int q = tid + NTHREADS * i;
-        if (!TA) { const int r = q >> 3; pa[i] = vaddr<TO, KA>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHA; pa[i] = vaddr<TO, KA>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
+        if (!TA) { const int r = q >> 3; pa[i] = vaddr<TO, KA, X2>(p.A, m0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHA; pa[i] = vaddr<TO, KA, X2>(p.A, k0 + k, m0 + ((q % TCHA) ^ tilet_swz(k)) * EPC); }
         sta[i] = pa[i] == zero_page ? 0u : (uint32_t)p.A.step;
       }
 #pragma unroll
       for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
         const int q = tid + NTHREADS * i;
-        if (!TB) { const int r = q >> 3; pb[i] = vaddr<TO, KB>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
-        else     { const int k = q / TCHB; pb[i] = vaddr<TO, KB>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
+        if (!TB) { const int r = q >> 3; pb[i] = vaddr<TO, KB, X2>(p.B, n0 + r, k0 + ((q & 7) ^ (r & 7)) * EPC); }
+        else     { const int k = q / TCHB; pb[i] = vaddr<TO, KB, X2>(p.B, k0 + k, n0 + ((q % TCHB) ^ tilet_swz(k)) * EPC); }
         stb[i] = pb[i] == zero_page ? 0u : (uint32_t)p.B.step;
       }
       until_slow = fast_tiles_after(kt);
@@ -869,7 +872,7 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   PT_STAMP(3);
   // every wave is past the loop's last barrier: the operand stages are dead and serve as per-row-block transposition scratch
   static_assert(Cfg::NWAVES * MI * SCRATCH_PER_WAVE <= NSTAGE * STAGE_BYTES, "stages hold one scratch per row block per wave");
-  gemm_epilogue<T, ATOMIC, MI, BM, BN>(p, acc, m0, n0, wm, wn, lane, smem + wave * (MI * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
+  gemm_epilogue<T, ATOMIC, MI, BM, BN, X2>(p, acc, m0, n0, wm, wn, lane, smem + wave * (MI * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
   PT_STAMP(5);
 }
 
@@ -901,7 +904,7 @@ constexpr int P8_UNIT = 16384, P8_BUF = 4 * P8_UNIT, P8_THREADS = 512;
 // / output gradients) e4m3 (1) or e5m2 (2): a k-tile is 128 elements -- the same 128-byte rows, unit images, swizzle and
 // staging schedule -- and the two 16-byte fragment reads of a row feed ONE v_mfma_f32_16x16x128_f8f6f4 instead of two
 // 16x16x32 bf16 MFMAs.  Which k a byte of a fragment stands for is irrelevant as long as both operands are read alike.
-template <bool TA, bool TB, int OUT, int KA, int KB, int F8 = 0>
+template <bool TA, bool TB, int OUT, int KA, int KB, int F8 = 0, bool X2 = false>
 __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, float* __restrict__ slab, char* smem) {
   using T = bf16_t;
   using TO = typename std::conditional<F8 != 0, f8_t, bf16_t>::type;     // operand element (addressing)
@@ -972,11 +975,11 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
         if (!TR) {
           const int u = q >> 3, c = (q & 7) ^ (u & 7);
           const int trow = OPER == 0 ? ((u >> 6) * 128 + S * 64 + (u & 63)) : ((u >> 5) * 64 + S * 32 + (u & 31));
-          ptr[U][i] = vaddr<TO, KC>(op, t0 + trow, k0 + c * EPC);
+          ptr[U][i] = vaddr<TO, KC, X2>(op, t0 + trow, k0 + c * EPC);
         } else {
           const int k = q >> 4, uc = ((q & 15) ^ tilet_swz(k)) * EPC;
           const int tcol = OPER == 0 ? ((uc >> 6) * 128 + S * 64 + (uc & 63)) : ((uc >> 5) * 64 + S * 32 + (uc & 31));
-          ptr[U][i] = vaddr<TO, KC>(op, k0 + k, t0 + tcol);
+          ptr[U][i] = vaddr<TO, KC, X2>(op, k0 + k, t0 + tcol);
         }
         stp[U][i] = ptr[U][i] == zero_page ? 0u : (uint32_t)op.step;
       }
@@ -1158,7 +1161,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
-  gemm_epilogue<T, ATOMIC, 8, BM, BN>(p, acc, m0, n0, wr, wc, lane, smem + wave * (8 * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
+  gemm_epilogue<T, ATOMIC, 8, BM, BN, X2>(p, acc, m0, n0, wr, wc, lane, smem + wave * (8 * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
 }
 
 __device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
@@ -1167,10 +1170,10 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
+template <bool TA, bool TB, bool ATOMIC, int KA, int KB, bool X2 = false>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm8p_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * P8_BUF];     // the ONLY LDS object (epilogue scratch aliases it)
-  gemm8p_body<TA, TB, ATOMIC ? 1 : 0, KA, KB>(p, xcd_contiguous_id(blockIdx.x, gridDim.x), nullptr, smem);
+  gemm8p_body<TA, TB, ATOMIC ? 1 : 0, KA, KB, 0, X2>(p, xcd_contiguous_id(blockIdx.x, gridDim.x), nullptr, smem);
 }
 
 template <int F8>
@@ -1319,12 +1322,12 @@ int check_operand(const pt_operand& o, int esize) {
   return PT_OK;
 }
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN>
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, int BM, int BN, bool X2 = false>
 int launch_cfg(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (int)((p.N + BN - 1) / BN);
   if ((int64_t)p.tiles_m * p.tiles_n * p.split_k >= (1ll << 31)) return PT_ERR_SHAPE;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM, BN>), grid, dim3(TileCfg<BM, BN>::NTHREADS), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, TA, TB, ATOMIC, KA, KB, BM, BN, 0, X2>), grid, dim3(TileCfg<BM, BN>::NTHREADS), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
@@ -1350,26 +1353,26 @@ inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
   return 128;
 }
 
-template <bool TA, bool TB, bool ATOMIC, int KA, int KB>
+template <bool TA, bool TB, bool ATOMIC, int KA, int KB, bool X2 = false>
 int launch_8p(GemmParams p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (int)((p.N + 255) / 256);
   if ((int64_t)p.tiles_m * p.tiles_n * p.split_k >= (1ll << 31)) return PT_ERR_SHAPE;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, 1);
-  hipLaunchKernelGGL((gemm8p_kernel<TA, TB, ATOMIC, KA, KB>), grid, dim3(P8_THREADS), 0, s, p);
+  hipLaunchKernelGGL((gemm8p_kernel<TA, TB, ATOMIC, KA, KB, X2>), grid, dim3(P8_THREADS), 0, s, p);
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
 
-template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB>
+template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, bool X2 = false>
 int launch(const GemmParams& p, hipStream_t s) {
   constexpr int cls = ATOMIC ? 4 : (!TB ? (KA == 0 ? 0 : 2) : (KA == 0 ? 1 : 3));
   int tile = pick_tile(p, cls, sizeof(T) == 2);
   if (p.arow_sum && tile != 128) tile = 128;            // the fused bias gradient lives in the two-stage 128 x 128 kernel
-  if constexpr (sizeof(T) == 2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB>(p, s); }
+  if constexpr (sizeof(T) == 2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB, X2>(p, s); }
   switch (tile) {
-    case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256>(p, s);
-    case 256: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 128>(p, s);
-    default: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 128, 128>(p, s);
+    case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256, X2>(p, s);
+    case 256: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 128, X2>(p, s);
+    default: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 128, 128, X2>(p, s);
   }
 }
 
@@ -1381,6 +1384,12 @@ int dispatch(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
   const bool atomic = p.out_kind == PT_OUT_F32_ATOMIC;
   const int ka = kind_class(p.A.kind), kb = kind_class(p.B.kind);
   if (!ta && !tb && !atomic && kb == 0) {                        // forward: linear / conv1x1 / conv k3
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (p.A.krep > 0) {                                        // PT_BF16X2 plane operands: their own instantiations
+        if (ka == 0) return launch<T, false, false, false, 0, 0, true>(p, s);
+        if (ka == 1) return launch<T, false, false, false, 1, 0, true>(p, s);
+      }
+    }
     if (ka == 0) return launch<T, false, false, false, 0, 0>(p, s);
     if (ka == 1) return launch<T, false, false, false, 1, 0>(p, s);
   }
