@@ -93,7 +93,8 @@ def pmc(fetch_db, write_db, out):
 
 def pmc_decode(fetch_db, write_db, out):
     """HBM-side bytes of ONE Encodec decode (`bench.py --only-decode`): the dispatches from one RVQ gather to the next."""
-    F, W = _per_step(fetch_db, "rvq_kernelI6bf16_t"), _per_step(write_db, "rvq_kernelI6bf16_t")
+    # the headline decode is the f32-class one (split storage): its RVQ gather is rvq_x2_kernel
+    F, W = _per_step(fetch_db, "rvq_x2_kernel"), _per_step(write_db, "rvq_x2_kernel")
     names = sorted(set(F) | set(W), key=lambda n: -(2 * F.get(n, [0, 0])[1] + W.get(n, [0, 0])[1]))
     dm = _demangle(names)
     kern = []
@@ -103,7 +104,7 @@ def pmc_decode(fetch_db, write_db, out):
         kern.append({"kernel": re.sub(r"\(anonymous namespace\)::", "", dm[n])[:160], "calls_per_decode": calls,
                      "read_bytes": rd, "write_bytes": wr})
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --only-decode`; one decode of "
-                     "64 x 1024 frames (bf16); FETCH_SIZE doubled (gfx950), unit 1024 B",
+                     "64 x 1024 frames (f32-class, split storage); FETCH_SIZE doubled (gfx950), unit 1024 B",
            "decode_read_bytes": sum(k["read_bytes"] for k in kern), "decode_write_bytes": sum(k["write_bytes"] for k in kern),
            "kernels": kern[:24]}
     res["decode_bytes"] = res["decode_read_bytes"] + res["decode_write_bytes"]
