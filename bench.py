@@ -516,12 +516,13 @@ def main():
             out["fp8_quantize"] = kern.get("pt_fp8_quantize")
         pmc = None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             if args.workload == "B" and args.dtype == "bf16" and not args.batch and os.path.exists(os.path.join(prof_dir, cand)):
                 with open(os.path.join(prof_dir, cand)) as f:
                     pmc = json.load(f)
                 out["roofline"]["traffic"] = pmc["step_bytes"]
-                out["roofline"]["traffic_note"] = f"HBM-side bytes of one step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/{cand})"
+                out["roofline"]["traffic_note"] = (f"HBM-side bytes of one step FROM THE COMMITTED PROFILE profiles/{cand} (rocprofv3 FETCH_SIZE x2 + "
+                                                   "WRITE_SIZE passes of `bench.py --no-replay`), not measured in this run")
                 break
         SYMBOL = {   # label -> kernel symbols of the class in the rocprofv3 summaries (which one a launch takes: csrc/gemm.hip pick_tile)
             "wgrad_group<bf16>/plain": ["wgrad8p_group_kernel<0>"], "wgrad_group<bf16>/conv": ["wgrad8p_group_kernel<1>"],
