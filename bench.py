@@ -304,6 +304,8 @@ def decode_bench(dev, prompts=64, T=1024, iters=8, dtype=torch.float32, cpu=True
            "hbm_view": hbm,
            "token_stage_ms": {"logits_head_plus_greedy": stage_ms[1], "logits_head_plus_top32": stage_ms[32]},
            "ar_generate": {"what": "ARCodecDecoder (d 512, 4 layers, 8 codebooks) greedy generate, %d prompts, ms per frame" % prompts,
+                           "decode_step": "folded launches (csrc/decode_step.hip: LN + Linear + epilogue / K-V append in one launch; 36 per frame, "
+                                          "round 3: ~70); same codes as the training kernels bit for bit",
                            "launch_by_launch": ar_eager, "hip_graph_replay": ar_graph,
                            "codec_tokens_per_s_graph": prompts * 8 / (ar_graph * 1e-3)},
            "audio_s_per_s_with_top32_token_stage": audio_s / ((ms + stage_ms[32]) * 1e-3),

@@ -47,7 +47,7 @@ enum pt_fp8_format { PT_FP8_E4M3 = 0, PT_FP8_E5M2 = 1 };   /* OCP fp8: e4m3 "fn"
 int pt_abi_version(void);                       /* bumps on any signature change */
 const char* pt_status_string(int status);
 const char* pt_last_hip_error(void);            /* hipGetErrorString of the HIP error behind the most recent PT_ERR_LAUNCH */
-int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc, 9 pt_transpose_seg */
+int pt_struct_size(int which);                  /* sizeof: 0 pt_operand, 1 pt_gemm_desc, 2 pt_attn_desc, 3 pt_param_seg, 4 pt_rowconv_desc, 5 pt_lstm2_desc, 6 pt_fold_seg, 7 pt_encodec_tail_desc, 8 pt_encodec_stage_desc, 9 pt_transpose_seg, 10 pt_decode_linear_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family.  C[m][n] (+)= sum_k VA(m,k) * VB(n,k) with f32 accumulation on MFMA.
@@ -467,6 +467,35 @@ int pt_codes_from_continuous(const float* x, int64_t* codes, int64_t n, int64_t 
  * over the k largest at `temperature`, inverse-CDF draw with the INJECTED uniform[row] in [0,1).  V <= 2048, k <= 64. */
 int pt_sample_topk(const void* logits, int64_t ld, const float* uniforms, int64_t* out, int64_t R, int64_t V, int64_t k,
                    float temperature, int dtype, pt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Autoregressive decode step (north_star; no reference counterpart): the launches of ONE frame for <= 64 prompts, folded.
+ * pt_decode_linear: y = epilogue([LayerNorm(x)] W^T) for M <= 64 rows, bf16, in one launch --
+ *   ln_gamma / ln_beta != NULL: nn.LayerNorm(K, ln_eps) applied to the rows of x first (K <= 512), with pt_layernorm_fwd's arithmetic;
+ *   bias [N] f32 or NULL, residual [M][ldr] bf16 or NULL (added after the bias), as pt_gemm;
+ *   geglu != 0: W is a GEGLU projection in the interleaved shadow order (pt_param_seg layout 2), N = 2F, bias in the ORIGINAL order;
+ *     y[m][F] = value * gelu_erf(gate) with the rounding points of pt_gemm followed by pt_geglu_fwd;
+ *   seg_cols > 0: output columns [seg_cols, 2 seg_cols) go to y2 + t_dev[0] * t_stride (row pitch ld2) and [2 seg_cols, 3 seg_cols)
+ *     to y3 + t_dev[0] * t_stride instead of y -- the fused q | k | v projection appending this frame's key and value to the
+ *     (B, T, C) caches at the DEVICE-resident frame index (a captured decode step replays with a new index each time).
+ * pt_ar_embed: out[b][:] = bf16(sum_q emb[q][prev[b][q]][:]) + pos[t_dev[0]][:]  (bf16; pt_rvq_decode + the position add).
+ * pt_ar_advance (after pt_sample_topk): prev[i] = idx[i]; codes[i][t] = idx[i] (codes (B, n_q, T) int64, i = b n_q + q);
+ *   t_dev[0] += 1; kv_len[b] += 1. */
+typedef struct pt_decode_linear_desc {
+  int64_t M, N, K;
+  const void* x; int64_t ldx;
+  const float* ln_gamma; const float* ln_beta; float ln_eps; int32_t geglu;
+  const void* w; int64_t ldw;
+  const float* bias;
+  const void* residual; int64_t ldr;
+  void* y; int64_t ldy;
+  int64_t seg_cols; void* y2; int64_t ld2; void* y3; int64_t ld3; const int64_t* t_dev; int64_t t_stride;
+} pt_decode_linear_desc;
+int pt_decode_linear(const pt_decode_linear_desc* d, pt_stream stream);
+int pt_ar_embed(const int64_t* prev, const void* emb, const void* pos, const int64_t* t_dev, void* out, int64_t B, int64_t n_q,
+                int64_t bins, int64_t dim, pt_stream stream);
+int pt_ar_advance(const int64_t* idx, int64_t* prev, int64_t* codes, int64_t* t_dev, int32_t* kv_len, int64_t B, int64_t n_q,
+                  int64_t T, pt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,14 @@ class pt_encodec_stage_desc(C.Structure):
                 ("wf", C.c_void_p), ("bf", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64)]
 
 
+class pt_decode_linear_desc(C.Structure):
+    _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("geglu", C.c_int32),
+                ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("y", C.c_void_p), ("ldy", C.c_int64), ("seg_cols", C.c_int64), ("y2", C.c_void_p), ("ld2", C.c_int64),
+                ("y3", C.c_void_p), ("ld3", C.c_int64), ("t_dev", C.c_void_p), ("t_stride", C.c_int64)]
+
+
 class pt_transpose_seg(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("src_ld", C.c_int64),
                 ("dst_ld", C.c_int64), ("tile_begin", C.c_int64)]
@@ -144,6 +152,9 @@ SIGNATURES = {
     "pt_encodec_res": [C.POINTER(pt_encodec_stage_desc), _i32, _vp],
     "pt_codes_from_continuous": [_vp, _vp, _i64, _i64, _vp],
     "pt_sample_topk": [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
+    "pt_decode_linear": [C.POINTER(pt_decode_linear_desc), _vp],
+    "pt_ar_embed": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+    "pt_ar_advance": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
 }
 
 
@@ -161,7 +172,7 @@ def _load():
     lib.pt_struct_size.argtypes = [C.c_int]
     lib.pt_wgrad_group_ws_floats.restype = C.c_int64
     lib.pt_wgrad_group_ws_floats.argtypes = [C.c_int]
-    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc, pt_encodec_stage_desc, pt_transpose_seg)):
+    for i, st in enumerate((pt_operand, pt_gemm_desc, pt_attn_desc, pt_param_seg, pt_rowconv_desc, pt_lstm2_desc, pt_fold_seg, pt_encodec_tail_desc, pt_encodec_stage_desc, pt_transpose_seg, pt_decode_linear_desc)):
         if lib.pt_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) disagrees with the library ({lib.pt_struct_size(i)} B)")
     for name, argtypes in SIGNATURES.items():

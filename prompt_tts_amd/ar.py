@@ -46,6 +46,9 @@ class LogitsHead(nn.Module):
 
 
 AR_GRAPH = __import__("os").environ.get("PT_AR_GRAPH", "1") != "0"     # capture the decode step of generate() as a HIP graph
+# the decode step on the folded launches of csrc/decode_step.hip (LN + Linear + epilogue in one launch, K / V appended by the
+# projection's epilogue, embedding / bookkeeping kernels): ~37 launches per frame instead of ~70.  PT_AR_FUSED=0: the training kernels.
+AR_FUSED = __import__("os").environ.get("PT_AR_FUSED", "1") != "0"
 
 
 class ARCodecDecoder(nn.Module):
@@ -139,6 +142,57 @@ class ARCodecDecoder(nn.Module):
         out, _ = blk.ff.fwd(st, n3, h2)
         return out
 
+    def _fusable(self, st, B):
+        """The folded decode step: bf16, <= 64 prompts, d_model <= 512 (the LayerNorm prologue holds a row per wave), fused q|k|v
+        weights and interleaved GEGLU projections in the store."""
+        if not AR_FUSED or st.dtype != torch.bfloat16 or B > 64 or self.d > 512 or self.d % 64:
+            return False
+        for blk in self.blocks:
+            a1 = blk.attn1
+            if st.fused([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]) is None:
+                return False
+            if id(blk.ff.net[0].proj.weight) not in st.geglu_ids or blk.attn2 is None:
+                return False
+        return True
+
+    def _block_step_fused(self, st, blk, h, cache, t_dev, kv_len, ctx2, B, S):
+        """One decode step of a block in 8 launches: [LN1 + q|k|v + cache append] attention [out + residual] [LN2 + q] cross-attention
+        [out + residual] [LN3 + GEGLU projection] [ff2 + residual] -- same arithmetic as _block_step, rounding point by rounding point."""
+        C, dev = self.d, h.device
+        a1, a2, ff = blk.attn1, blk.attn2, blk.ff
+        kc, vc = cache
+        Tm = kc.shape[1]
+        q = torch.empty(B, C, dtype=h.dtype, device=dev)
+        fw = st.fused([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight])[0]
+        ops.decode_linear(h, fw, q, B, 3 * C, C, ln=(st.f(blk.norm1.weight), st.f(blk.norm1.bias)), seg_cols=C,
+                          y2=kc, ld2=Tm * C, y3=vc, ld3=Tm * C, t_dev=t_dev, t_stride=C)
+        o = torch.empty(B, C, dtype=h.dtype, device=dev)
+        lse = torch.empty(B, self.heads, 1, dtype=torch.float32, device=dev)
+        ops.attn_fwd(q, kc.view(B * Tm, C), vc.view(B * Tm, C), o, lse, B, self.heads, 1, Tm, C // self.heads, a1.scale, False, kv_len)
+        h1 = torch.empty_like(h)
+        ops.decode_linear(o, st.w(a1.to_out[0].weight), h1, B, C, C, bias=st.f(a1.to_out[0].bias), residual=h)
+        q2 = torch.empty(B, C, dtype=h.dtype, device=dev)
+        ops.decode_linear(h1, st.w(a2.to_q.weight), q2, B, C, C, ln=(st.f(blk.norm2.weight), st.f(blk.norm2.bias)))
+
+        def project_kv():
+            fkv = st.fused([a2.to_k.weight, a2.to_v.weight])
+            if fkv is not None:
+                buf = E.linear_fwd(ctx2, fkv[0])
+                return buf[:, :C], buf[:, C:], buf
+            return E.linear_fwd(ctx2, st.w(a2.to_k.weight)), E.linear_fwd(ctx2, st.w(a2.to_v.weight)), None
+        k2, v2, _ = E.cached_cross_kv(a2, ctx2, project_kv)               # the prompt's K / V: projected once per generate()
+        o2 = torch.empty(B, C, dtype=h.dtype, device=dev)
+        ops.attn_fwd(q2, k2, v2, o2, lse, B, a2.heads, 1, S, a2.dim_head, a2.scale, False, None)
+        h2 = torch.empty_like(h)
+        ops.decode_linear(o2, st.w(a2.to_out[0].weight), h2, B, C, C, bias=st.f(a2.to_out[0].bias), residual=h1)
+        p1, p2 = ff.net[0].proj, ff.net[2]
+        F2 = p1.weight.shape[0]
+        act = torch.empty(B, F2 // 2, dtype=h.dtype, device=dev)
+        ops.decode_linear(h2, st.w(p1.weight), act, B, F2, C, ln=(st.f(blk.norm3.weight), st.f(blk.norm3.bias)), bias=st.f(p1.bias), geglu=True)
+        out = torch.empty_like(h)
+        ops.decode_linear(act, st.w(p2.weight), out, B, C, F2 // 2, bias=st.f(p2.bias), residual=h2)
+        return out
+
     @torch.no_grad()
     def generate(self, ctx, T, k=1, uniforms=None, temperature=1.0, graph=None):
         """ctx (B, S, d_ctx) -> codes (B, n_q, T) int64.  k = 1: greedy argmax; k > 1: top-k sampling, one INJECTED uniform per
@@ -162,8 +216,12 @@ class ARCodecDecoder(nn.Module):
         if graph is None:
             graph = AR_GRAPH
         n_eager = T if not graph or T < 4 else 2
+        fused = self._fusable(st, B)
+        # frames on the training kernels: all the launch-by-launch ones, or -- with the folded decode step -- only frame 0 (the BOS row);
+        # the folded step then runs launch by launch up to n_eager and as a replayed graph after it: the same kernels either way
+        first = min(1, T) if fused else n_eager
         with E.cross_kv_cache():
-            for t in range(n_eager):
+            for t in range(first):
                 h = self._embed(st, prev, t0=t)
                 kv_len = torch.full((B,), t + 1, dtype=torch.int32, device=dev)
                 for blk, cache in zip(self.blocks, caches):
@@ -173,15 +231,27 @@ class ARCodecDecoder(nn.Module):
                 idx = ops.sample_topk(logits, k=k, uniforms=uniforms[t].contiguous() if k > 1 else None, temperature=temperature)
                 prev = idx.view(B, self.n_q, 1)
                 codes[:, :, t] = prev[:, :, 0]
-            if n_eager < T:
+            if first < T:
                 # ---- the decode step with every per-frame quantity on the device ----
-                t_dev = torch.full((1,), n_eager, dtype=torch.int64, device=dev)
-                kv_len = torch.full((B,), n_eager + 1, dtype=torch.int32, device=dev)
+                t_dev = torch.full((1,), first, dtype=torch.int64, device=dev)
+                kv_len = torch.full((B,), first + 1, dtype=torch.int32, device=dev)
                 prev_buf = prev.contiguous().clone()
                 pos = self._pos.to(st.dtype)
                 emb = st.w(self.code_embedding)
 
                 def step():
+                    if fused:
+                        h = torch.empty(B, self.d, dtype=st.dtype, device=dev)
+                        ops.ar_embed(prev_buf, emb, pos, t_dev, h, B, self.n_q, self.bins, self.d)
+                        for blk, cache in zip(self.blocks, caches):
+                            h = self._block_step_fused(st, blk, h, cache, t_dev, kv_len, ctx2, B, S)
+                        logits = torch.empty(B, self.n_q * self.bins, dtype=st.dtype, device=dev)
+                        ops.decode_linear(h, st.w(self.head.proj.weight), logits, B, self.n_q * self.bins, self.d,
+                                          ln=(st.f(self.norm_out.weight), st.f(self.norm_out.bias)), bias=st.f(self.head.proj.bias))
+                        u = uniforms.index_select(0, t_dev).view(-1) if k > 1 else None
+                        idx = ops.sample_topk(logits.view(B * self.n_q, self.bins), k=k, uniforms=u, temperature=temperature)
+                        ops.ar_advance(idx, prev_buf, codes, t_dev, kv_len, B, self.n_q, T)
+                        return
                     x = torch.empty(B, self.d, dtype=st.dtype, device=dev)
                     ops.rvq_decode(prev_buf, emb, x, B, self.n_q, 1, self.bins, self.d)
                     h = (x + pos.index_select(0, t_dev)).contiguous()
@@ -197,15 +267,18 @@ class ARCodecDecoder(nn.Module):
 
                 if k > 1:
                     uniforms = uniforms.contiguous()
+                for _ in range(first, n_eager):
+                    step()
                 g = None
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        step()
-                except RuntimeError as e:                    # e.g. another capture in progress on this device: same step, launch by launch
-                    import warnings
-                    warnings.warn(f"ARCodecDecoder.generate: HIP graph capture failed ({e}); running the decode step launch by launch")
-                    g = None
+                if n_eager < T:
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            step()
+                    except RuntimeError as e:                # e.g. another capture in progress on this device: same step, launch by launch
+                        import warnings
+                        warnings.warn(f"ARCodecDecoder.generate: HIP graph capture failed ({e}); running the decode step launch by launch")
+                        g = None
                 for _ in range(n_eager, T):
                     if g is not None:
                         g.replay()

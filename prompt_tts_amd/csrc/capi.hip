@@ -1,7 +1,7 @@
 // ABI bookkeeping for the C library.
 #include "common.h"
 
-extern "C" int pt_abi_version(void) { return 23; }
+extern "C" int pt_abi_version(void) { return 24; }
 
 thread_local int pt_g_last_hip_error = 0;      // per calling thread: concurrent callers do not overwrite each other's error
 extern "C" const char* pt_last_hip_error(void) { return hipGetErrorString((hipError_t)pt_g_last_hip_error); }
@@ -30,6 +30,7 @@ extern "C" int pt_struct_size(int which) {
     case 7: return (int)sizeof(pt_encodec_tail_desc);
     case 8: return (int)sizeof(pt_encodec_stage_desc);
     case 9: return (int)sizeof(pt_transpose_seg);
+    case 10: return (int)sizeof(pt_decode_linear_desc);
     default: return -1;
   }
 }

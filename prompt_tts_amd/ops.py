@@ -439,3 +439,35 @@ def replay_captured(captured, label, rounds=3):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (rounds * len(sel))
     return len(sel), us, sum(f for _, _, f in sel) / len(sel) / us / 1e6
+
+
+# ---- autoregressive decode step (M <= 64 rows; csrc/decode_step.hip) ---------------------------------------------------------
+def decode_linear(x, w, out, M, N, K, ln=None, eps=1e-5, bias=None, residual=None, geglu=False, seg_cols=0, y2=None, ld2=0, y3=None, ld3=0,
+                  t_dev=None, t_stride=0):
+    """out = epilogue([LayerNorm(x)] w^T): one launch for LN + Linear + bias + residual / GEGLU / the K-V cache scatter."""
+    _dev(x, w, out)
+    d = L.pt_decode_linear_desc()
+    d.M, d.N, d.K = M, N, K
+    d.x, d.ldx = x.data_ptr(), x.stride(0)
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), eps
+    d.geglu = int(geglu)
+    d.w, d.ldw = w.data_ptr(), w.stride(0)
+    d.bias = _p(bias)
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.y, d.ldy = out.data_ptr(), out.stride(0)
+    d.seg_cols = seg_cols
+    if seg_cols:
+        d.y2, d.ld2, d.t_dev, d.t_stride = y2.data_ptr(), ld2, t_dev.data_ptr(), t_stride
+        if y3 is not None:
+            d.y3, d.ld3 = y3.data_ptr(), ld3
+    check(lib.pt_decode_linear(C.byref(d), _stream()), "pt_decode_linear")
+
+
+def ar_embed(prev, emb, pos, t_dev, out, B, n_q, bins, dim):
+    check(lib.pt_ar_embed(_p(prev), _p(emb), _p(pos), _p(t_dev), _p(out), B, n_q, bins, dim, _stream()), "pt_ar_embed")
+
+
+def ar_advance(idx, prev, codes, t_dev, kv_len, B, n_q, T):
+    check(lib.pt_ar_advance(_p(idx), _p(prev), _p(codes), _p(t_dev), _p(kv_len), B, n_q, T, _stream()), "pt_ar_advance")

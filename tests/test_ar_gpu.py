@@ -109,3 +109,82 @@ def test_generate_graph_replay_equals_launch_by_launch(dev, k, dtype):
     assert a.shape == (B, 4, T) and torch.equal(a, b) and len(torch.unique(a)) > 10
     c = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=True)      # a second capture in the same process
     assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("M,K,N,mode", [(64, 512, 1536, "qkv"), (37, 256, 256, "plain"), (64, 2048, 512, "res"), (5, 512, 4096, "geglu"),
+                                        (64, 512, 8192, "ln_bias")])
+def test_decode_linear_equals_the_separate_launches_bit_for_bit(dev, M, K, N, mode):
+    """pt_decode_linear ([LayerNorm ->] Linear [-> bias] [-> + residual] [-> GEGLU] [-> K / V cache scatter], M <= 64 rows, one
+    launch) against the launches it folds -- pt_layernorm_fwd, pt_gemm, pt_geglu_fwd, index_copy_ -- on the same inputs: the SAME
+    bits (same rounding points, same accumulation order), and a torch f32 reference within bf16 tolerance."""
+    from prompt_tts_amd import engine as E, ops
+    g = torch.Generator().manual_seed(M + K + N)
+    bf = torch.bfloat16
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(dev, bf)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev, bf)
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dev); beta = (0.1 * torch.randn(K, generator=g)).to(dev)
+    if mode == "qkv":
+        C, Tm = N // 3, 7
+        kc = torch.zeros(M, Tm, C, device=dev, dtype=bf); vc = torch.zeros_like(kc)
+        kc2, vc2 = kc.clone(), vc.clone()
+        t_dev = torch.full((1,), 4, dtype=torch.int64, device=dev)
+        q = torch.empty(M, C, device=dev, dtype=bf)
+        ops.decode_linear(x, w, q, M, N, K, ln=(gamma, beta), seg_cols=C, y2=kc, ld2=Tm * C, y3=vc, ld3=Tm * C, t_dev=t_dev, t_stride=C)
+        n1, _ = E.layernorm_fwd(x, gamma, beta)
+        qkv = E.linear_fwd(n1, w)
+        kc2.index_copy_(1, t_dev, qkv[:, C:2 * C].unsqueeze(1)); vc2.index_copy_(1, t_dev, qkv[:, 2 * C:].unsqueeze(1))
+        assert torch.equal(q, qkv[:, :C]) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+        ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta) @ w.float().t()
+        assert relerr(q, ref[:, :C]) < 3e-2
+    elif mode in ("plain", "res"):
+        res = (torch.randn(M, N, generator=g)).to(dev, bf) if mode == "res" else None
+        y = torch.empty(M, N, device=dev, dtype=bf)
+        ops.decode_linear(x, w, y, M, N, K, bias=bias, residual=res)
+        want = E.linear_fwd(x, w, bias, residual=res)
+        assert torch.equal(y, want)
+        ref = x.float() @ w.float().t() + bias + (res.float() if res is not None else 0)
+        assert relerr(y, ref) < 2e-2
+    elif mode == "ln_bias":
+        y = torch.empty(M, N, device=dev, dtype=bf)
+        ops.decode_linear(x, w, y, M, N, K, ln=(gamma, beta), bias=bias)
+        n1, _ = E.layernorm_fwd(x, gamma, beta)
+        assert torch.equal(y, E.linear_fwd(n1, w, bias))
+    else:
+        # GEGLU: w rows in the interleaved shadow order (value row 32 q + t at 64 q + t, its gate at 64 q + 32 + t), bias in the original order
+        F = N // 2
+        perm = torch.empty(N, dtype=torch.int64)
+        for mi in range(N):
+            qq, t = mi >> 6, mi & 63
+            perm[mi] = 32 * qq + t if t < 32 else F + 32 * qq + (t - 32)
+        wi = w[perm.to(dev)].contiguous()
+        act = torch.empty(M, F, device=dev, dtype=bf)
+        ops.decode_linear(x, wi, act, M, N, K, ln=(gamma, beta), bias=bias, geglu=True)
+        n1, _ = E.layernorm_fwd(x, gamma, beta)
+        proj = E.linear_fwd(n1, wi)
+        want = torch.empty(M, F, device=dev, dtype=bf)
+        ops.geglu_fwd(proj, want, bias=bias, interleaved=True)
+        assert torch.equal(act, want)
+        pr = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta) @ w.float().t() + bias
+        ref = pr[:, :F] * torch.nn.functional.gelu(pr[:, F:])
+        assert relerr(act, ref) < 3e-2
+
+
+@pytest.mark.parametrize("k", [1, 8])
+def test_folded_decode_step_makes_the_training_kernels_decisions(dev, k, monkeypatch):
+    """generate() on the folded launches of csrc/decode_step.hip (~37 per frame) against the same loop on the training kernels
+    (PT_AR_FUSED=0, ~70 per frame): the codes must be IDENTICAL -- the folded kernels keep every rounding point and accumulation
+    order of the launches they replace."""
+    import prompt_tts_amd.ar as par
+    _, m = _pair(dev, torch.bfloat16, seed=9)
+    g = torch.Generator().manual_seed(11)
+    B, T, S = 5, 48, 24
+    ctx = torch.randn(B, S, 256, generator=g).to(dev)
+    u = torch.rand(T, B * 4, generator=g).to(dev)
+    assert m._fusable(m.store, B)
+    a = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=True)
+    b = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=False)
+    monkeypatch.setattr(par, "AR_FUSED", False)
+    assert not m._fusable(m.store, B)
+    c = m.generate(ctx, T, k=k, uniforms=u if k > 1 else None, temperature=0.8, graph=False)
+    assert torch.equal(a, b) and torch.equal(a, c) and len(torch.unique(a)) > 10
