@@ -496,6 +496,19 @@ int pt_ar_embed(const int64_t* prev, const void* emb, const void* pos, const int
                 int64_t bins, int64_t dim, pt_stream stream);
 int pt_ar_advance(const int64_t* idx, int64_t* prev, int64_t* codes, int64_t* t_dev, int32_t* kv_len, int64_t B, int64_t n_q,
                   int64_t T, pt_stream stream);
+/* dst[0 .. n) = src[t_dev[0] * ld .. + n)  (f32; the row of injected uniforms of the device-resident frame index). */
+int pt_row_select(const float* src, int64_t ld, const int64_t* t_dev, float* dst, int64_t n, pt_stream stream);
+
+/* A fixed sequence of launches issued by ONE call: the decode step's ~36 launches have constant arguments from frame to frame (every
+ * per-frame quantity lives on the device), so the host builds the list once and replays it with one call per frame -- 2-3 us of
+ * host time per launch instead of a Python round trip each, and no graph capture needed.  Stops at the first non-zero status. */
+enum pt_op_kind { PT_OP_DECODE_LINEAR = 0, PT_OP_ATTN_FWD = 1, PT_OP_AR_EMBED = 2, PT_OP_SAMPLE_TOPK = 3, PT_OP_AR_ADVANCE = 4, PT_OP_ROW_SELECT = 5 };
+typedef struct pt_ar_embed_desc { const int64_t* prev; const void* emb; const void* pos; const int64_t* t_dev; void* out; int64_t B, n_q, bins, dim; } pt_ar_embed_desc;
+typedef struct pt_sample_desc { const void* logits; int64_t ld; const float* uniforms; int64_t* out; int64_t R, V, k; float temperature; int32_t dtype; } pt_sample_desc;
+typedef struct pt_ar_advance_desc { const int64_t* idx; int64_t* prev; int64_t* codes; int64_t* t_dev; int32_t* kv_len; int64_t B, n_q, T; } pt_ar_advance_desc;
+typedef struct pt_row_select_desc { const float* src; int64_t ld; const int64_t* t_dev; float* dst; int64_t n; } pt_row_select_desc;
+typedef struct pt_op { int32_t kind; int32_t dtype; const void* desc; } pt_op;   /* dtype: PT_OP_ATTN_FWD only */
+int pt_run_ops(const pt_op* ops, int64_t n, pt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,32 @@ class pt_decode_linear_desc(C.Structure):
                 ("y3", C.c_void_p), ("ld3", C.c_int64), ("t_dev", C.c_void_p), ("t_stride", C.c_int64)]
 
 
+class pt_ar_embed_desc(C.Structure):
+    _fields_ = [("prev", C.c_void_p), ("emb", C.c_void_p), ("pos", C.c_void_p), ("t_dev", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int64), ("n_q", C.c_int64), ("bins", C.c_int64), ("dim", C.c_int64)]
+
+
+class pt_sample_desc(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("ld", C.c_int64), ("uniforms", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64),
+                ("V", C.c_int64), ("k", C.c_int64), ("temperature", C.c_float), ("dtype", C.c_int32)]
+
+
+class pt_ar_advance_desc(C.Structure):
+    _fields_ = [("idx", C.c_void_p), ("prev", C.c_void_p), ("codes", C.c_void_p), ("t_dev", C.c_void_p), ("kv_len", C.c_void_p),
+                ("B", C.c_int64), ("n_q", C.c_int64), ("T", C.c_int64)]
+
+
+class pt_row_select_desc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int64), ("t_dev", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
+
+
+class pt_op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("desc", C.c_void_p)]
+
+
+PT_OP_DECODE_LINEAR, PT_OP_ATTN_FWD, PT_OP_AR_EMBED, PT_OP_SAMPLE_TOPK, PT_OP_AR_ADVANCE, PT_OP_ROW_SELECT = range(6)
+
+
 class pt_transpose_seg(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("src_ld", C.c_int64),
                 ("dst_ld", C.c_int64), ("tile_begin", C.c_int64)]
@@ -155,6 +181,8 @@ SIGNATURES = {
     "pt_decode_linear": [C.POINTER(pt_decode_linear_desc), _vp],
     "pt_ar_embed": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pt_ar_advance": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "pt_row_select": [_vp, _i64, _vp, _vp, _i64, _vp],
+    "pt_run_ops": [C.POINTER(pt_op), _i64, _vp],
 }
 
 

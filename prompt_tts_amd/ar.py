@@ -51,6 +51,117 @@ AR_GRAPH = __import__("os").environ.get("PT_AR_GRAPH", "1") != "0"     # capture
 AR_FUSED = __import__("os").environ.get("PT_AR_FUSED", "1") != "0"
 
 
+AR_OPLIST = __import__("os").environ.get("PT_AR_OPLIST", "1") != "0"   # the folded step as ONE pt_run_ops call per frame (else per launch)
+
+
+class _FoldedStep:
+    """The folded decode step as a FIXED list of launches (pt_run_ops): every buffer is allocated once, every descriptor built once
+    -- the per-frame quantities (frame index, K/V length, previous codes, uniforms row) live on the device -- and a frame is one
+    C-ABI call that issues the ~36 launches back to back (no Python between them, nothing to capture)."""
+
+    def __init__(self, model, st, caches, ctx2, B, S, T, k, uniforms, temperature, t_dev, kv_len, prev_buf, codes):
+        import ctypes as C
+        from . import _lib as L
+        self.C, self.L = C, L
+        dev, bf, d = ctx2.device, st.dtype, model.d
+        self.keep, self.ops = [], []
+        new = lambda *shape, dtype=bf: self._keep(torch.empty(*shape, dtype=dtype, device=dev))
+        pos = self._keep(model._pos.to(bf)); emb = st.w(model.code_embedding)
+        h = new(B, d)
+        e = L.pt_ar_embed_desc()
+        e.prev, e.emb, e.pos, e.t_dev, e.out = prev_buf.data_ptr(), emb.data_ptr(), pos.data_ptr(), t_dev.data_ptr(), h.data_ptr()
+        e.B, e.n_q, e.bins, e.dim = B, model.n_q, model.bins, d
+        self._op(L.PT_OP_AR_EMBED, e)
+        lse = new(B, model.heads, 1, dtype=torch.float32)
+        for blk, (kc, vc) in zip(model.blocks, caches):
+            a1, a2, ff = blk.attn1, blk.attn2, blk.ff
+            Tm = kc.shape[1]
+            q, o, h1, q2, o2, h2, out = (new(B, d) for _ in range(7))
+            fw = st.fused([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight])[0]
+            self._lin(h, fw, q, B, 3 * d, d, ln=blk.norm1, st=st, seg_cols=d, y2=kc, ld2=Tm * d, y3=vc, ld3=Tm * d, t_dev=t_dev, t_stride=d)
+            self._attn(q, kc.view(B * Tm, d), vc.view(B * Tm, d), o, lse, B, model.heads, Tm, d // model.heads, a1.scale, kv_len)
+            self._lin(o, st.w(a1.to_out[0].weight), h1, B, d, d, bias=st.f(a1.to_out[0].bias), residual=h)
+            self._lin(h1, st.w(a2.to_q.weight), q2, B, d, d, ln=blk.norm2, st=st)
+            k2, v2 = self._cross_kv(st, a2, ctx2, d)
+            self._attn(q2, k2, v2, o2, lse, B, a2.heads, S, a2.dim_head, a2.scale, None)
+            self._lin(o2, st.w(a2.to_out[0].weight), h2, B, d, d, bias=st.f(a2.to_out[0].bias), residual=h1)
+            p1, p2 = ff.net[0].proj, ff.net[2]
+            F2 = p1.weight.shape[0]
+            act = new(B, F2 // 2)
+            self._lin(h2, st.w(p1.weight), act, B, F2, d, ln=blk.norm3, st=st, bias=st.f(p1.bias), geglu=True)
+            self._lin(act, st.w(p2.weight), out, B, d, F2 // 2, bias=st.f(p2.bias), residual=h2)
+            h = out
+        NV = model.n_q * model.bins
+        logits = new(B, NV)
+        self._lin(h, st.w(model.head.proj.weight), logits, B, NV, d, ln=model.norm_out, st=st, bias=st.f(model.head.proj.bias))
+        idx = new(B * model.n_q, dtype=torch.int64)
+        u = None
+        if k > 1:
+            u = new(B * model.n_q, dtype=torch.float32)
+            r = L.pt_row_select_desc()
+            r.src, r.ld, r.t_dev, r.dst, r.n = uniforms.data_ptr(), uniforms.stride(0), t_dev.data_ptr(), u.data_ptr(), B * model.n_q
+            self._op(L.PT_OP_ROW_SELECT, r)
+        sd = L.pt_sample_desc()
+        sd.logits, sd.ld, sd.uniforms, sd.out = logits.data_ptr(), model.bins, (u.data_ptr() if u is not None else None), idx.data_ptr()
+        sd.R, sd.V, sd.k, sd.temperature, sd.dtype = B * model.n_q, model.bins, k, temperature, ops._DT[bf]
+        self._op(L.PT_OP_SAMPLE_TOPK, sd)
+        ad = L.pt_ar_advance_desc()
+        ad.idx, ad.prev, ad.codes, ad.t_dev, ad.kv_len = idx.data_ptr(), prev_buf.data_ptr(), codes.data_ptr(), t_dev.data_ptr(), kv_len.data_ptr()
+        ad.B, ad.n_q, ad.T = B, model.n_q, T
+        self._op(L.PT_OP_AR_ADVANCE, ad)
+        self.keep += [uniforms, t_dev, kv_len, prev_buf, codes, caches, ctx2]
+        self.arr = (L.pt_op * len(self.ops))(*self.ops)
+
+    def _keep(self, t):
+        self.keep.append(t)
+        return t
+
+    def _op(self, kind, desc, dtype=0):
+        self.keep.append(desc)
+        o = self.L.pt_op()
+        o.kind, o.dtype, o.desc = kind, dtype, self.C.cast(self.C.pointer(desc), self.C.c_void_p)
+        self.ops.append(o)
+
+    def _lin(self, x, w, out, M, N, K, ln=None, st=None, bias=None, residual=None, geglu=False, seg_cols=0, y2=None, ld2=0, y3=None, ld3=0,
+             t_dev=None, t_stride=0):
+        d = self.L.pt_decode_linear_desc()
+        d.M, d.N, d.K, d.x, d.ldx = M, N, K, x.data_ptr(), x.stride(0)
+        if ln is not None:
+            g, b = st.f(ln.weight), st.f(ln.bias)
+            d.ln_gamma, d.ln_beta, d.ln_eps = g.data_ptr(), b.data_ptr(), ln.eps
+            self.keep += [g, b]
+        d.geglu, d.w, d.ldw = int(geglu), w.data_ptr(), w.stride(0)
+        if bias is not None:
+            d.bias = bias.data_ptr()
+        if residual is not None:
+            d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+        d.y, d.ldy, d.seg_cols = out.data_ptr(), out.stride(0), seg_cols
+        if seg_cols:
+            d.y2, d.ld2, d.y3, d.ld3, d.t_dev, d.t_stride = y2.data_ptr(), ld2, y3.data_ptr(), ld3, t_dev.data_ptr(), t_stride
+        self.keep += [x, w, out, bias, residual]
+        self._op(self.L.PT_OP_DECODE_LINEAR, d)
+
+    def _attn(self, q, kk, vv, o, lse, B, H, Nk, D, scale, kv_len):
+        d = ops.attn_desc(q, kk, vv, o, lse, B, H, 1, Nk, D, scale, False, kv_len)
+        self.keep += [q, kk, vv, o, lse, kv_len]
+        self._op(self.L.PT_OP_ATTN_FWD, d, ops._DT[q.dtype])
+
+    def _cross_kv(self, st, a2, ctx2, C_):
+        def project_kv():
+            fkv = st.fused([a2.to_k.weight, a2.to_v.weight])
+            if fkv is not None:
+                buf = E.linear_fwd(ctx2, fkv[0])
+                return buf[:, :C_], buf[:, C_:], buf
+            return E.linear_fwd(ctx2, st.w(a2.to_k.weight)), E.linear_fwd(ctx2, st.w(a2.to_v.weight)), None
+        k2, v2, buf = E.cached_cross_kv(a2, ctx2, project_kv)
+        self.keep += [k2, v2, buf]
+        return k2, v2
+
+    def run(self):
+        from ._lib import lib, check
+        check(lib.pt_run_ops(self.arr, len(self.ops), ops._stream()), "pt_run_ops")
+
+
 class ARCodecDecoder(nn.Module):
     def __init__(self, d_model=512, n_layers=4, n_q=8, bins=1024, heads=8, cross_attention_dim=None, max_frames=1024,
                  dtype=torch.bfloat16):
@@ -145,7 +256,7 @@ class ARCodecDecoder(nn.Module):
     def _fusable(self, st, B):
         """The folded decode step: bf16, <= 64 prompts, d_model <= 512 (the LayerNorm prologue holds a row per wave), fused q|k|v
         weights and interleaved GEGLU projections in the store."""
-        if not AR_FUSED or st.dtype != torch.bfloat16 or B > 64 or self.d > 512 or self.d % 64:
+        if not AR_FUSED or st.dtype != torch.bfloat16 or B > 64 or self.d not in (256, 512):
             return False
         for blk in self.blocks:
             a1 = blk.attn1
@@ -213,10 +324,12 @@ class ARCodecDecoder(nn.Module):
                   for _ in self.blocks]
         codes = torch.zeros(B, self.n_q, T, dtype=torch.int64, device=dev)
         prev = torch.zeros(B, self.n_q, 1, dtype=torch.int64, device=dev)
-        if graph is None:
-            graph = AR_GRAPH
-        n_eager = T if not graph or T < 4 else 2
         fused = self._fusable(st, B)
+        if graph is None:
+            # the folded step as ONE pt_run_ops call per frame issues its launches back to back from C: faster than replaying them as a
+            # HIP graph (0.376 vs 0.415 ms per frame, tools/ar_probe.py), so the graph is the default only for the unfolded step
+            graph = AR_GRAPH and not (fused and AR_OPLIST)
+        n_eager = T if not graph or T < 4 else 2
         # frames on the training kernels: all the launch-by-launch ones, or -- with the folded decode step -- only frame 0 (the BOS row);
         # the folded step then runs launch by launch up to n_eager and as a replayed graph after it: the same kernels either way
         first = min(1, T) if fused else n_eager
@@ -239,7 +352,16 @@ class ARCodecDecoder(nn.Module):
                 pos = self._pos.to(st.dtype)
                 emb = st.w(self.code_embedding)
 
+                folded = None
+                if fused and AR_OPLIST:
+                    if k > 1:
+                        uniforms = uniforms.contiguous()
+                    folded = _FoldedStep(self, st, caches, ctx2, B, S, T, k, uniforms, temperature, t_dev, kv_len, prev_buf, codes)
+
                 def step():
+                    if folded is not None:
+                        folded.run()
+                        return
                     if fused:
                         h = torch.empty(B, self.d, dtype=st.dtype, device=dev)
                         ops.ar_embed(prev_buf, emb, pos, t_dev, h, B, self.n_q, self.bins, self.d)

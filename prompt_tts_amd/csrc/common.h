@@ -129,6 +129,22 @@ __device__ __forceinline__ void gelu_erf_fast(float x, float& gelu, float& dgelu
   dgelu = cdf + x * 0.39894228040143267794f * e;
 }
 
+// LayerNorm arithmetic shared by ln_fwd_kernel (norms.hip) and the LayerNorm prologue of pt_decode_linear (decode_step.hip), with
+// the multiply-add fusion spelled out: under -ffp-contract=fast the backend fuses where it sees fit, and it saw fit differently in
+// the two kernels -- the same source expression gave f32 values one ulp apart, i.e. one bf16 ulp whenever the value sits on a
+// rounding boundary (1 element in ~30 000; enough to flip a sampler near-tie a few frames later).
+__device__ __forceinline__ float pt_ln_sq_acc(float ss, float d) { return __builtin_fmaf(d, d, ss); }
+__device__ __forceinline__ float pt_ln_rstd(float ss, float n, float eps) {
+#pragma clang fp contract(off)
+  const float var = ss / n;
+  return rsqrtf(var + eps);
+}
+__device__ __forceinline__ float pt_ln_apply(float v, float mu, float rs, float g, float b) {
+#pragma clang fp contract(off)
+  const float t = (v - mu) * rs;
+  return __builtin_fmaf(t, g, b);
+}
+
 // host-side launch check
 extern thread_local int pt_g_last_hip_error;      // capi.hip: the hipError_t behind this thread's most recent PT_ERR_LAUNCH (diagnostics)
 #define PT_LAUNCH_CHECK()                                  \

@@ -10,6 +10,7 @@
 // same lane -> column map and reduction order; the product as pt_gemm: one f32 accumulator per output element advanced by
 // v_mfma_f32_16x16x32_bf16 steps of ascending k; bias, residual and GEGLU as gemm_epilogue / geglu_fwd_kernel), so that the fused
 // step makes the decisions of the launch-by-launch step bit for bit (tests/test_ar_gpu.py).
+#include <type_traits>
 #include "mma.h"
 
 namespace {
@@ -32,70 +33,75 @@ __device__ __forceinline__ float dl_gelu(float x) { return 0.5f * x * (1.f + erf
 
 // Workgroup = 16 output columns, wave w = row tile w (rows 16 w .. 16 w + 15): N / 16 workgroups stream the weights (a 64-column
 // workgroup put 8 CUs on an N = 512 layer and walked K = 2048 in four dependent chunks: 17 / 46 us per launch), and every output
-// element is still ONE accumulator advanced in ascending k.  With the LayerNorm prologue a wave normalises its own 16 rows (all
-// requested at once) into its private LDS rows and reads them back as A fragments; without it the A fragments come straight from
-// global memory, in chunks of 256 columns requested one chunk ahead of the products that use them (as are the weights).
+// element is still ONE accumulator advanced in ascending k.  With the LayerNorm prologue (LN_NKS = K / 32 = 8 or 16) a wave
+// normalises its own 16 rows (all requested at once) into its private LDS rows and reads them back as A fragments; without it
+// (LN_NKS = 0, K a multiple of 256) the A fragments come straight from global memory, in chunks of 256 columns requested one
+// chunk ahead of the products that use them (as are the weights).  NO load is predicated: rows past M and columns past N read a
+// valid row instead and are simply never stored (per-load conditions made the compiler wait for every load by itself and branch
+// around every product: 12 us per launch, the same kernel as a straight run of loads then products: see DESIGN.md).
+template <int LN_NKS>
 __global__ __launch_bounds__(256) void dlin_kernel(const DlinParams p) {
-  __shared__ __attribute__((aligned(16))) char xs[DL_ROWS * DL_PITCH];
+  __shared__ __attribute__((aligned(16))) char xs[LN_NKS ? DL_ROWS * DL_PITCH : 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   // weight row of this lane's B-operand column.  plain: 16 blockIdx + li.  GEGLU (interleaved rows: per 64, 32 values then their 32
   // gates): workgroup j = (q, w) = (j / 4, j % 4) takes value rows 64 q + 8 w + li (li < 8) and the gates of the same eight activation
   // columns (li >= 8), so that accumulator rows 4 g + r of lane groups g and g + 2 are value and gate of one column
   const int jq = blockIdx.x >> 2, jw = blockIdx.x & 3;
-  const int nrow = p.geglu ? 64 * jq + (li < 8 ? 8 * jw + li : 32 + 8 * jw + (li - 8)) : 16 * blockIdx.x + li;
-  const bool nok = nrow < p.N;
-  const bf16_t* wrow = p.w + (int64_t)(nok ? nrow : 0) * p.ldw + 8 * g;
+  int nrow = p.geglu ? 64 * jq + (li < 8 ? 8 * jw + li : 32 + 8 * jw + (li - 8)) : 16 * blockIdx.x + li;
+  nrow = nrow < p.N ? nrow : p.N - 1;
+  const bf16_t* wrow = p.w + (int64_t)nrow * p.ldw + 8 * g;
   const int m = 16 * wave + li;                                 // this lane's activation row (A fragment) / output row
   const bool mok = m < p.M;
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // what the epilogue adds is requested up front (loaded where it is used, every launch ended in two more load round trips)
   const int nb = 16 * blockIdx.x + 4 * g;                       // plain epilogue: this lane's 4 consecutive output columns
+  const bool nbok = nb < p.N;
   float eb[4] = {0.f, 0.f, 0.f, 0.f};
   u32x2_t er = {0u, 0u};
   int64_t tcur = 0;
   if (!p.geglu) {
-    if (p.bias && nb < p.N) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) eb[r] = p.bias[nb + r];
+    if (p.bias) {
+      const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + (nbok ? nb : 0));
+      eb[0] = bv[0]; eb[1] = bv[1]; eb[2] = bv[2]; eb[3] = bv[3];
     }
-    if (p.residual && mok && nb < p.N) er = *reinterpret_cast<const u32x2_t*>(p.residual + (int64_t)m * p.ldr + nb);
+    if (p.residual) er = *reinterpret_cast<const u32x2_t*>(p.residual + (int64_t)(mok ? m : 0) * p.ldr + (nbok ? nb : 0));
     if (p.seg_cols > 0) tcur = p.t_dev[0];
   } else if (p.bias) {
-    const int c0 = 32 * jq + 8 * jw + 4 * (g & 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) eb[r] = p.bias[(g < 2 ? 0 : (p.N >> 1)) + c0 + r];
+    const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + (g < 2 ? 0 : (p.N >> 1)) + 32 * jq + 8 * jw + 4 * (g & 1));
+    eb[0] = bv[0]; eb[1] = bv[1]; eb[2] = bv[2]; eb[3] = bv[3];
   }
-  if (p.gamma) {
+  if constexpr (LN_NKS > 0) {
     // LayerNorm of a row by one wave (ln_fwd_kernel<bf16_t, 1>: lane holds the 8 columns lane * 8 ..): rows 16 wave .. + 15
+    constexpr int K = 32 * LN_NKS;
     char* xw = xs + 16 * wave * DL_PITCH;
     const int col = lane * 8;
-    const bool cok = col < p.K;
+    const bool cok = col < K;
+    const int colc = cok ? col : 0;
     Vec16<bf16_t> vin[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int r = 16 * wave + i;
-      vin[i] = zero16<bf16_t>();
-      if (r < p.M && cok) vin[i] = load16(p.x + (int64_t)r * p.ldx + col);
+      int r = 16 * wave + i; r = r < p.M ? r : p.M - 1;
+      vin[i] = load16(p.x + (int64_t)r * p.ldx + colc);
     }
-    Frag<bf16_t> wf[DL_KC / 32];                                // the weights travel while the rows are normalised
+    Frag<bf16_t> wf[LN_NKS];                                    // the weights travel while the rows are normalised
 #pragma unroll
-    for (int ks = 0; ks < DL_KC / 32; ++ks) {
-      if (nok && 32 * ks < p.K) frag_load_global(wf[ks], wrow + 32 * ks); else frag_zero(wf[ks]);
+    for (int ks = 0; ks < LN_NKS; ++ks) frag_load_global(wf[ks], wrow + 32 * ks);
+    float gm[8], bt[8];
+    {
+      const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(p.gamma + colc), g1 = *reinterpret_cast<const f32x4_t*>(p.gamma + colc + 4);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.beta + colc), b1 = *reinterpret_cast<const f32x4_t*>(p.beta + colc + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gm[e] = g0[e]; gm[4 + e] = g1[e]; bt[e] = b0[e]; bt[4 + e] = b1[e]; }
     }
     // the 16 rows' wave reductions advance TOGETHER (each is wave_sum's butterfly, v += shfl_xor(v, 32, 16, .. 1), unchanged per row:
     // one row after the other, 32 dependent cross-lane steps of ~100 cycles each were 8 of a launch's 20 us)
-    float gm[8], bt[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { gm[e] = cok ? p.gamma[col + e] : 0.f; bt[e] = cok ? p.beta[col + e] : 0.f; }
     float mu[16], rs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float s = 0.f;
-      if (cok) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += vin[i].get(e);
-      }
-      mu[i] = s;
+      for (int e = 0; e < 8; ++e) s += vin[i].get(e);
+      mu[i] = cok ? s : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -103,62 +109,55 @@ __global__ __launch_bounds__(256) void dlin_kernel(const DlinParams p) {
       for (int i = 0; i < 16; ++i) mu[i] += __shfl_xor(mu[i], o, 64);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      mu[i] = mu[i] / (float)p.K;
+      mu[i] = mu[i] / (float)K;
       float ss = 0.f;
-      if (cok) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = vin[i].get(e) - mu[i]; ss += d * d; }
-      }
-      rs[i] = ss;
+      for (int e = 0; e < 8; ++e) { const float d = vin[i].get(e) - mu[i]; ss = pt_ln_sq_acc(ss, d); }
+      rs[i] = cok ? ss : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
       for (int i = 0; i < 16; ++i) rs[i] += __shfl_xor(rs[i], o, 64);
+    if (cok) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = 16 * wave + i;
-      Vec16<bf16_t> o = zero16<bf16_t>();
-      if (r < p.M && cok) {
-        const float rstd = rsqrtf(rs[i] / (float)p.K + p.eps);
+      for (int i = 0; i < 16; ++i) {
+        Vec16<bf16_t> o;
+        const float rstd = pt_ln_rstd(rs[i], (float)K, p.eps);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, (vin[i].get(e) - mu[i]) * rstd * gm[e] + bt[e]);
+        for (int e = 0; e < 8; ++e) o.set(e, pt_ln_apply(vin[i].get(e), mu[i], rstd, gm[e], bt[e]));
+        *reinterpret_cast<u32x4_t*>(xw + i * DL_PITCH + col * 2) = o.raw;
       }
-      *reinterpret_cast<u32x4_t*>(xw + i * DL_PITCH + col * 2) = o.raw;
     }
     __syncthreads();
+    Frag<bf16_t> fa[LN_NKS];
 #pragma unroll
-    for (int ks = 0; ks < DL_KC / 32; ++ks) {
-      if (32 * ks < p.K) {
-        Frag<bf16_t> fa;
-        fa.v = *reinterpret_cast<const bf16x8_t*>(xw + li * DL_PITCH + (32 * ks + 8 * g) * 2);
-        mma16(acc, wf[ks], fa);                                 // D[row = column 4 g + r of the 16][col = row 16 wave + li]
-      }
-    }
+    for (int ks = 0; ks < LN_NKS; ++ks) fa[ks].v = *reinterpret_cast<const bf16x8_t*>(xw + li * DL_PITCH + (32 * ks + 8 * g) * 2);
+#pragma unroll
+    for (int ks = 0; ks < LN_NKS; ++ks) mma16(acc, wf[ks], fa[ks]);   // D[row = column 4 g + r of the 16][col = row 16 wave + li]
   } else {
     constexpr int CH = 8;                                       // k-steps per chunk (256 columns)
-    const bf16_t* xrow = p.x + (int64_t)(mok ? m : 0) * p.ldx + 8 * g;
-    const int nks = p.K / 32;
+    const bf16_t* xrow = p.x + (int64_t)(mok ? m : p.M - 1) * p.ldx + 8 * g;
+    const int nch = p.K / (32 * CH);
     Frag<bf16_t> wa[2][CH], xa[2][CH];
-    auto request = [&](int buf, int ks0) {
+    auto request = [&](auto buf_c, int ch) {
+      constexpr int buf = decltype(buf_c)::value;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        if (ks0 + k < nks) {
-          if (nok) frag_load_global(wa[buf][k], wrow + 32 * (ks0 + k)); else frag_zero(wa[buf][k]);
-          if (mok) frag_load_global(xa[buf][k], xrow + 32 * (ks0 + k)); else frag_zero(xa[buf][k]);
-        }
+        frag_load_global(wa[buf][k], wrow + 32 * (CH * ch + k));
+        frag_load_global(xa[buf][k], xrow + 32 * (CH * ch + k));
       }
     };
-    request(0, 0);
-    for (int ks0 = 0; ks0 < nks; ks0 += 2 * CH) {               // two chunks per trip: buffer indices stay compile-time
-      if (ks0 + CH < nks) request(1, ks0 + CH);
+    request(std::integral_constant<int, 0>{}, 0);
+    for (int ch = 0; ch < nch; ch += 2) {                       // two chunks per trip: buffer indices stay compile-time
+      if (ch + 1 < nch) request(std::integral_constant<int, 1>{}, ch + 1);
 #pragma unroll
-      for (int k = 0; k < CH; ++k)
-        if (ks0 + k < nks) mma16(acc, wa[0][k], xa[0][k]);
-      if (ks0 + 2 * CH < nks) request(0, ks0 + 2 * CH);
+      for (int k = 0; k < CH; ++k) mma16(acc, wa[0][k], xa[0][k]);
+      if (ch + 2 < nch) request(std::integral_constant<int, 0>{}, ch + 2);
+      if (ch + 1 < nch) {
 #pragma unroll
-      for (int k = 0; k < CH; ++k)
-        if (ks0 + CH + k < nks) mma16(acc, wa[1][k], xa[1][k]);
+        for (int k = 0; k < CH; ++k) mma16(acc, wa[1][k], xa[1][k]);
+      }
     }
   }
   // ---- epilogue: lane (li, g) holds, for row m, the workgroup's columns 4 g + r ----
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void dlin_kernel(const DlinParams p) {
     }
     return;
   }
-  if (nb >= p.N || !mok) return;
+  if (!nbok || !mok) return;
   bf16_t* dst = p.y; int64_t ldd = p.ldy; int ncol = nb;
   if (p.seg_cols > 0) {                                         // column segments: 0 -> y, 1 -> y2 (+ t), 2 -> y3 (+ t)
     const int seg = nb / p.seg_cols;
@@ -241,14 +240,55 @@ __global__ __launch_bounds__(256) void ar_advance_kernel(const int64_t* __restri
   if (threadIdx.x == 0) t_dev[0] = t + 1;
 }
 
+__global__ __launch_bounds__(256) void row_select_kernel(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ t_dev,
+                                                         float* __restrict__ dst, int64_t n) {
+  const float* row = src + t_dev[0] * ld;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = row[i];
+}
+
 }  // namespace
+
+extern "C" int pt_row_select(const float* src, int64_t ld, const int64_t* t_dev, float* dst, int64_t n, pt_stream stream) {
+  if (!src || !t_dev || !dst || n <= 0) return PT_ERR_ARG;
+  int64_t blocks = (n + 255) / 256; if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, t_dev, dst, n);
+  PT_LAUNCH_CHECK();
+  return PT_OK;
+}
+
+extern "C" int pt_run_ops(const pt_op* ops, int64_t n, pt_stream stream) {
+  if (!ops || n <= 0) return PT_ERR_ARG;
+  for (int64_t i = 0; i < n; ++i) {
+    const pt_op& o = ops[i];
+    if (!o.desc) return PT_ERR_ARG;
+    int st;
+    switch (o.kind) {
+      case PT_OP_DECODE_LINEAR: st = pt_decode_linear(static_cast<const pt_decode_linear_desc*>(o.desc), stream); break;
+      case PT_OP_ATTN_FWD: st = pt_attn_fwd(static_cast<const pt_attn_desc*>(o.desc), o.dtype, stream); break;
+      case PT_OP_AR_EMBED: { const auto* d = static_cast<const pt_ar_embed_desc*>(o.desc);
+        st = pt_ar_embed(d->prev, d->emb, d->pos, d->t_dev, d->out, d->B, d->n_q, d->bins, d->dim, stream); } break;
+      case PT_OP_SAMPLE_TOPK: { const auto* d = static_cast<const pt_sample_desc*>(o.desc);
+        st = pt_sample_topk(d->logits, d->ld, d->uniforms, d->out, d->R, d->V, d->k, d->temperature, d->dtype, stream); } break;
+      case PT_OP_AR_ADVANCE: { const auto* d = static_cast<const pt_ar_advance_desc*>(o.desc);
+        st = pt_ar_advance(d->idx, d->prev, d->codes, d->t_dev, d->kv_len, d->B, d->n_q, d->T, stream); } break;
+      case PT_OP_ROW_SELECT: { const auto* d = static_cast<const pt_row_select_desc*>(o.desc);
+        st = pt_row_select(d->src, d->ld, d->t_dev, d->dst, d->n, stream); } break;
+      default: return PT_ERR_ARG;
+    }
+    if (st != PT_OK) return st;
+  }
+  return PT_OK;
+}
 
 extern "C" int pt_decode_linear(const pt_decode_linear_desc* d, pt_stream stream) {
   if (!d) return PT_ERR_ARG;
   if (d->M <= 0 || d->M > DL_ROWS || d->N <= 0 || d->K <= 0 || d->K % 32 != 0 || d->N % 4 != 0) return PT_ERR_SHAPE;
   if (!d->x || !d->w || !d->y) return PT_ERR_ARG;
   if (!pt_aligned16(d->x) || (d->ldx * 2) % 16 || !pt_aligned16(d->w) || (d->ldw * 2) % 16 || (reinterpret_cast<uintptr_t>(d->y) & 7u) || d->ldy % 4) return PT_ERR_ALIGN;
-  if (d->ln_gamma && (!d->ln_beta || d->K > DL_KC)) return PT_ERR_SHAPE;
+  // LayerNorm prologue: K = 256 or 512 (a row per wave, a compile-time number of k-steps); without it K is walked in chunks of 256
+  if (d->ln_gamma ? (!d->ln_beta || (d->K != 256 && d->K != 512)) : (d->K % 256 != 0)) return PT_ERR_SHAPE;
+  if (d->ln_gamma && ((reinterpret_cast<uintptr_t>(d->ln_gamma) & 15u) || (reinterpret_cast<uintptr_t>(d->ln_beta) & 15u))) return PT_ERR_ALIGN;
+  if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15u)) return PT_ERR_ALIGN;
   if (d->residual && ((reinterpret_cast<uintptr_t>(d->residual) & 7u) || d->ldr % 4)) return PT_ERR_ALIGN;
   if (d->geglu && (d->N % 64 != 0 || d->residual || d->seg_cols)) return PT_ERR_ARG;
   if (d->seg_cols) {
@@ -261,7 +301,13 @@ extern "C" int pt_decode_linear(const pt_decode_linear_desc* d, pt_stream stream
   p.w = (const bf16_t*)d->w; p.ldw = d->ldw; p.bias = d->bias; p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr;
   p.y = (bf16_t*)d->y; p.ldy = d->ldy; p.geglu = d->geglu ? 1 : 0;
   p.seg_cols = (int)d->seg_cols; p.y2 = (bf16_t*)d->y2; p.ld2 = d->ld2; p.y3 = (bf16_t*)d->y3; p.ld3 = d->ld3; p.t_dev = d->t_dev; p.t_stride = d->t_stride;
-  hipLaunchKernelGGL(dlin_kernel, dim3((unsigned)((d->N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)((d->N + 15) / 16));
+  if (d->ln_gamma) {
+    if (d->K == 256) hipLaunchKernelGGL(dlin_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dlin_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(dlin_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  }
   PT_LAUNCH_CHECK();
   return PT_OK;
 }

@@ -41,10 +41,10 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, con
     const int col = (lane + 64 * j) * EPC;
     if (col < C) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { float d = v[j].get(e) - mu; ss += d * d; }
+      for (int e = 0; e < EPC; ++e) { float d = v[j].get(e) - mu; ss = pt_ln_sq_acc(ss, d); }
     }
   }
-  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  const float rs = pt_ln_rstd(wave_sum(ss), (float)C, eps);      // (explicit fusion choices: common.h, shared with pt_decode_linear)
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   T* yr = y + row * C;
 #pragma unroll
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, con
     if (col < C) {
       Vec16<T> o;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o.set(e, (v[j].get(e) - mu) * rs * gamma[col + e] + beta[col + e]);
+      for (int e = 0; e < EPC; ++e) o.set(e, pt_ln_apply(v[j].get(e), mu, rs, gamma[col + e], beta[col + e]));
       store16(yr + col, o);
     }
   }

@@ -112,7 +112,8 @@ def test_generate_graph_replay_equals_launch_by_launch(dev, k, dtype):
 
 
 @pytest.mark.parametrize("M,K,N,mode", [(64, 512, 1536, "qkv"), (37, 256, 256, "plain"), (64, 2048, 512, "res"), (5, 512, 4096, "geglu"),
-                                        (64, 512, 8192, "ln_bias")])
+                                        (64, 512, 8192, "ln_bias"), (64, 512, 512, "res"), (3, 1024, 256, "res"), (64, 256, 768, "qkv"),
+                                        (64, 256, 2048, "geglu"), (64, 512, 512, "ln_bias")])
 def test_decode_linear_equals_the_separate_launches_bit_for_bit(dev, M, K, N, mode):
     """pt_decode_linear ([LayerNorm ->] Linear [-> bias] [-> + residual] [-> GEGLU] [-> K / V cache scatter], M <= 64 rows, one
     launch) against the launches it folds -- pt_layernorm_fwd, pt_gemm, pt_geglu_fwd, index_copy_ -- on the same inputs: the SAME
@@ -168,6 +169,25 @@ def test_decode_linear_equals_the_separate_launches_bit_for_bit(dev, M, K, N, mo
         pr = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta) @ w.float().t() + bias
         ref = pr[:, :F] * torch.nn.functional.gelu(pr[:, F:])
         assert relerr(act, ref) < 3e-2
+
+
+@pytest.mark.parametrize("K", [256, 512])
+def test_decode_linear_layernorm_is_pt_layernorm_fwd_bit_for_bit(dev, K):
+    """The LayerNorm prologue of pt_decode_linear (through an identity weight) against pt_layernorm_fwd on 200 x 64 rows of varied
+    scale and offset: EVERY element the same bf16 bits.  (Compiled from the same source expression the two kernels once differed
+    in 1 element of ~30 000 -- the backend fused multiply-adds differently -- which flipped sampler near-ties a few frames on.)"""
+    from prompt_tts_amd import engine as E, ops
+    g = torch.Generator(device=dev).manual_seed(K)
+    eye = torch.eye(K, device=dev, dtype=torch.bfloat16)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g, device=dev)); beta = 0.2 * torch.randn(K, generator=g, device=dev)
+    bad = 0
+    for trial in range(200):
+        x = (torch.randn(64, K, generator=g, device=dev) * (0.05 + 0.1 * trial) + 0.01 * trial).to(torch.bfloat16)
+        ref, _ = E.layernorm_fwd(x, gamma, beta)
+        got = torch.empty_like(x)
+        ops.decode_linear(x, eye, got, 64, K, K, ln=(gamma, beta))
+        bad += int((ref != got).sum())
+    assert bad == 0, bad
 
 
 @pytest.mark.parametrize("k", [1, 8])
