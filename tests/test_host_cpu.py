@@ -174,6 +174,33 @@ def test_cabi_refuses_bad_arguments_with_a_status_never_a_launch():
     assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 12, 0, L.PT_BF16, None) == -1
     assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 16, 0, 9, None) == -2                # unknown dtype
     assert lib.pt_geglu_fwd(OKP, None, OKP, 16, 16, 1, L.PT_BF16, None) == -1       # interleaved needs F % 32 == 0
+    # round 4: split storage (PT_BF16X2) and the folded decode step
+    x2 = L.pt_gemm_desc.from_buffer_copy(d); x2.M, x2.N, x2.K, x2.ldc, x2.A.ld, x2.B.ld = 128, 128, 64, 256, 128, 128
+    bad = L.pt_gemm_desc.from_buffer_copy(x2); bad.A.trans = 1
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # plane operands: forward GEMMs only
+    bad = L.pt_gemm_desc.from_buffer_copy(x2); bad.ldc = 128
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # a plane row holds 2 N elements
+    bad = L.pt_gemm_desc.from_buffer_copy(x2); bad.x2_block = 48
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # the plane block must divide N
+    assert lib.pt_gemm(ctypes.byref(x2), 7, None) == -2                             # unknown dtype
+    l2 = L.pt_lstm2_desc(); l2.B, l2.T, l2.H, l2.per_step = 4, 10, 512, 1
+    for f in ("x", "xg0", "whh0", "wcat1", "bias1", "h0_seq", "h1_seq", "c0", "c1", "out_elu"):
+        setattr(l2, f, OKP)
+    assert lib.pt_lstm2_forward(ctypes.byref(l2), L.PT_BF16X2, None) == -1          # plane rows: the persistent f32-class form only
+    dl = L.pt_decode_linear_desc(); dl.M, dl.N, dl.K, dl.x, dl.ldx, dl.w, dl.ldw, dl.y, dl.ldy = 64, 512, 512, OKP, 512, OKP, 512, OKP, 512
+    bad = L.pt_decode_linear_desc.from_buffer_copy(dl); bad.M = 65
+    assert lib.pt_decode_linear(ctypes.byref(bad), None) == -1                      # at most 64 rows
+    bad = L.pt_decode_linear_desc.from_buffer_copy(dl); bad.K = 384
+    assert lib.pt_decode_linear(ctypes.byref(bad), None) == -1                      # K walks in chunks of 256
+    bad = L.pt_decode_linear_desc.from_buffer_copy(dl); bad.ln_gamma = OKP; bad.ln_beta = OKP; bad.K = 1024
+    assert lib.pt_decode_linear(ctypes.byref(bad), None) == -1                      # LayerNorm prologue: K = 256 or 512
+    bad = L.pt_decode_linear_desc.from_buffer_copy(dl); bad.seg_cols = 512; bad.N = 1536
+    assert lib.pt_decode_linear(ctypes.byref(bad), None) == -5                      # column segments need their destinations
+    assert lib.pt_run_ops(None, 3, None) == -5
+    op = L.pt_op(); op.kind = 99; op.desc = OKP
+    assert lib.pt_run_ops(ctypes.byref(op), 1, None) == -5                          # unknown op kind
+    assert lib.pt_ar_advance(OKP, OKP, OKP, OKP, OKP, 0, 8, 16, None) == -1
+    assert lib.pt_row_select(OKP, 64, None, OKP, 64, None) == -5
 
 
 def test_product_never_imports_oracle_or_reference():
