@@ -285,6 +285,7 @@ def decode_bench(dev, prompts=64, T=1024, iters=8, dtype=torch.float32, cpu=True
     out = {"metric": "generated-audio-seconds/sec (Encodec 24 kHz decode)", "value": audio_s / (ms * 1e-3), "unit": "audio-s/s",
            "ms_per_batch": ms, "prompts": prompts, "frames": T,
            "dtype": "bf16" if dtype == torch.bfloat16 else "f32-class (f32 accumulate / bias / ELU, products as bf16 x 3 splits, activations stored as hi + lo bf16 planes)",
+           "breakdown_ms": {k: round(v["ms_total"], 3) for k, v in per.items()},      # HIP events around every C-ABI call of one decode
            "lstm_ms": lstm_ms, "lstm_steps_per_s": 2 * T / (lstm_ms * 1e-3) if lstm_ms else None,
            "lstm_us_per_tick": lstm_ms * 1e3 / (T + 1) if lstm_ms else None,
            "achieved_tflops": flops / (ms * 1e-3) / 1e12,
