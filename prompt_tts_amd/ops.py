@@ -364,7 +364,7 @@ def profile_one_step(step_fn, capture=None):
 
     def label_and_flops(name, args):
         if name == "pt_gemm":
-            d = args[0]._obj; dt = "bf16" if args[1] == L.PT_BF16 else "f32"
+            d = args[0]._obj; dt = {L.PT_BF16: "bf16", L.PT_BF16X2: "f32-class/x2"}.get(args[1], "f32")
             kind = ("N", "T")[d.A.trans] + ("N", "T")[d.B.trans]
             conv = "conv" if L.PT_V_CONV in (d.A.kind, d.B.kind) else "plain"
             return f"gemm<{dt},{kind},{'atomic' if d.out_kind == L.PT_OUT_F32_ATOMIC else 'store'}>/{conv}", gemm_flops(d)
