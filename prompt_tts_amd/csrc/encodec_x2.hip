@@ -22,6 +22,23 @@
 
 namespace {
 
+// Diagnostic build (-DX2_TRACE=1, `make exp`): lane 0 of waves 0 and 5 of workgroup 0 stamps s_memtime at the phase boundaries of
+// its first 8 tiles (tools/x2_trace.py prints the differences)
+#ifndef X2_TRACE
+#define X2_TRACE 0
+#endif
+#if X2_TRACE
+__device__ unsigned long long x2_trace_buf[3 * 2 * 8 * 16];
+#define XT_STAMP(k, w2, i) do { if (blockIdx.x == 0 && xt_it < 8 && lane == 0 && (wave == 0 || wave == (w2))) \
+    x2_trace_buf[(((k) * 2 + (wave != 0)) * 8 + xt_it) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XT_NEXT ++xt_it
+#define XT_DECL int xt_it = 0
+#else
+#define XT_STAMP(k, w2, i) do { } while (0)
+#define XT_NEXT do { } while (0)
+#define XT_DECL do { } while (0)
+#endif
+
 __device__ __forceinline__ float x2_elu(float v) { return v < 0.f ? (__expf(v) - 1.f) : v; }
 
 // 8 consecutive f32 weights -> register-resident hi / lo B fragment
@@ -52,6 +69,14 @@ __device__ __forceinline__ bf16x8_t x2_frag8(const char* p) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 __device__ __forceinline__ bf16x8_t x2_frag16(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+// LDS images of plane rows without padding: the 16-byte chunk c of row r is stored at chunk c ^ f(r).  Rows are read as B fragments
+// (ds_read_b128, lane (li, g) -> row li + const, chunk g + const) and written four channels (8 bytes) at a time from product
+// layout (lane (li, g) -> row li or 4 li + const, byte 8 g + const); tools/lds_model.py counts, for each candidate stride / f, the
+// LDS cycles of those instructions under the bank rules of MI355X_MICROARCH.md: the 136- / 72-byte strides of this file's first
+// version (8-byte aligned rows, hence ds_read2_b64 at half the read rate) cost 8 cycles a read and 16 a write (4-way conflict
+// between rows 4 apart), these 4 - 7 and 8.
+__device__ __forceinline__ int x2_sw128(int row, int chunk) { return row * 128 + ((chunk ^ ((row ^ (row >> 2)) & 7)) << 4); }   // 64-channel rows
+__device__ __forceinline__ int x2_sw64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }             // 32-channel rows
 __device__ __forceinline__ bf16x8_t x2_bzero() {
   const u32x4_t z = {0u, 0u, 0u, 0u};
   return __builtin_bit_cast(bf16x8_t, z);
@@ -70,7 +95,7 @@ __device__ __forceinline__ void x2_elu8(const u32x4_t h, const u32x4_t l, u32x4_
 // =====================================================================================================================
 // residual block, 128 channels:  x1 (raw planes) -> ELU -> causal conv k3 (128 -> 64) -> ELU -> 1x1 ([64 | 128] -> 128) -> ELU
 // =====================================================================================================================
-constexpr int XR_C = 128, XR_ROWS = 64, XR_OWN = 62, XR_XS = 272, XR_S3 = 136;
+constexpr int XR_C = 128, XR_ROWS = 64, XR_OWN = 62, XR_XS = 288, XR_S3 = 128;   // x1 rows padded to 16 x 18 bytes, c3e rows swizzled (x2_sw128)
 constexpr int XR_XPLANE = XR_ROWS * XR_XS, XR_3PLANE = XR_ROWS * XR_S3;
 struct X2ResParams {
   int B, n;
@@ -83,9 +108,9 @@ struct X2ResParams {
 
 __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * XR_XPLANE + 2 * XR_3PLANE];
-  char* X1r = smem;                           // [2 planes][64 rows][272 B]
+  char* X1r = smem;                           // [2 planes][64 rows][288 B]
   char* X1e = X1r + 2 * XR_XPLANE;            // ELU(x1); reused for the output tile
-  char* C3e = X1e + 2 * XR_XPLANE;            // [2 planes][64][136 B]
+  char* C3e = X1e + 2 * XR_XPLANE;            // [2 planes][64][128 B], chunks swizzled
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   // k3 conv: wave = (column tile nt3 = wave & 3, row half wave >> 2); 1x1: wave = column tile of the 128 outputs, all four row tiles
   const int nt3 = wave & 3, rh = wave >> 2;
@@ -139,17 +164,17 @@ __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResPara
       const int j = 16 * (2 * rh + rr) + li, t = t_base + j;
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
-        const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
-        const bool ok = sj >= 0 && sj < XR_ROWS;
+        // rows before the tile belong to the halo rows of a tile that does not start an item: their results are never used, so
+        // the row index is clamped instead of the load being predicated (a predicated load became a branch around every product)
+        const int v = t + tap - 2, sj0 = (v < 0 ? -v : v) - t_base, sj = sj0 < 0 ? 0 : sj0;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           FragX3 fa;
-          if (ok) { fa.hi = x2_frag16(X1e + sj * XR_XS + 64 * kk + 16 * g); fa.lo = x2_frag16(X1e + XR_XPLANE + sj * XR_XS + 64 * kk + 16 * g); }
-          else fa = x2_zero();
+          fa.hi = x2_frag16(X1e + sj * XR_XS + 64 * kk + 16 * g); fa.lo = x2_frag16(X1e + XR_XPLANE + sj * XR_XS + 64 * kk + 16 * g);
           mma16x3(acc, w3[4 * tap + kk], fa);                  // D[row = channel 16 nt3 + 4 g + r][col = row j]
         }
       }
-      char* dst = C3e + j * XR_S3 + (16 * nt3 + 4 * g) * 2;
+      char* dst = C3e + x2_sw128(j, 2 * nt3 + (g >> 1)) + 8 * (g & 1);
       x2_store4(dst, dst + XR_3PLANE, x2_elu(acc[0] + b34[0]), x2_elu(acc[1] + b34[1]), x2_elu(acc[2] + b34[2]), x2_elu(acc[3] + b34[3]));
     }
     __syncthreads();
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResPara
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) {
         FragX3 fa;
-        if (ks < 2) { fa.hi = x2_frag8(C3e + j * XR_S3 + 64 * ks + 16 * g); fa.lo = x2_frag8(C3e + XR_3PLANE + j * XR_S3 + 64 * ks + 16 * g); }
+        if (ks < 2) { const int off = x2_sw128(j, 4 * ks + g); fa.hi = x2_frag16(C3e + off); fa.lo = x2_frag16(C3e + XR_3PLANE + off); }
         else { fa.hi = x2_frag16(X1r + j * XR_XS + 64 * (ks - 2) + 16 * g); fa.lo = x2_frag16(X1r + XR_XPLANE + j * XR_XS + 64 * (ks - 2) + 16 * g); }
         mma16x3(acc[rt], wf[ks], fa);
       }
@@ -192,8 +217,11 @@ __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResPara
 //           -> 1x1 ([32 | 64] -> 64) -> ELU -> out (planes, 64 ch, 4 n rows)
 // =====================================================================================================================
 constexpr int X2S_CIN = 128, X2S_C = 64, X2S_RIN = 30, X2S_HALO = 2, X2S_RI = 32, X2S_RO = 128;
-constexpr int X2S_XS = 272, X2S_S1 = 136, X2S_S3 = 72, X2S_WFS = 208;
-constexpr int X2S_XPLANE = X2S_RI * X2S_XS, X2S_1PLANE = X2S_RO * X2S_S1, X2S_3PLANE = X2S_RO * X2S_S3, X2S_WPLANE = 64 * X2S_WFS;
+// every fragment is ONE ds_read_b128 (ds_read2_b64, what two 8-byte reads become, runs at half its rate, and the k3 / 1x1 phases
+// were bound by the LDS: tools/x2_trace.py); input / weight rows are padded to 16 bytes x (2 mod 4), the conflict-free strides for
+// the fragment read, x1 / c3e rows are unpadded and chunk-swizzled (x2_sw128 / x2_sw64)
+constexpr int X2S_XS = 288, X2S_S1 = 128, X2S_S3 = 64, X2S_W3S = 416, X2S_W3PLANE = 32 * X2S_W3S, X2S_WFS = 224, X2S_WFPLANE = 64 * X2S_WFS;
+constexpr int X2S_XPLANE = X2S_RI * X2S_XS, X2S_1PLANE = X2S_RO * X2S_S1, X2S_3PLANE = X2S_RO * X2S_S3;
 struct X2StageParams {
   int B, n;
   const bf16_t* x; int64_t ldx;            // [B*n][ldx]: hi 0..127, lo 128..255
@@ -205,15 +233,17 @@ struct X2StageParams {
 };
 
 __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2StageParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * X2S_XPLANE + 4 * X2S_1PLANE + 2 * X2S_3PLANE + 2 * X2S_WPLANE + (256 + 32 + 64) * 4];
-  char* Xin = smem;                           // [2][32][272]
-  char* X1r = Xin + 2 * X2S_XPLANE;           // [2][128][136]
-  char* X1e = X1r + 2 * X2S_1PLANE;           // [2][128][136]; reused for the output tile
-  char* C3e = X1e + 2 * X2S_1PLANE;           // [2][128][72]
-  char* Wfs = C3e + 2 * X2S_3PLANE;           // [2][64 rows][208 B]: hi / lo of the 1x1 weights
-  float* Bts = reinterpret_cast<float*>(Wfs + 2 * X2S_WPLANE);   // biases (read where they are added: 16 registers a lane)
+  __shared__ __attribute__((aligned(16))) char smem[2 * X2S_XPLANE + 4 * X2S_1PLANE + 2 * X2S_3PLANE + 2 * X2S_W3PLANE + 2 * X2S_WFPLANE + (256 + 32 + 64) * 4 + 64];
+  char* Xin = smem;                           // [2][32][288]
+  char* X1r = Xin + 2 * X2S_XPLANE;           // [2][128][128], chunks swizzled
+  char* X1e = X1r + 2 * X2S_1PLANE;           // the same; reused for the output tile
+  char* C3e = X1e + 2 * X2S_1PLANE;           // [2][128][64], chunks swizzled
+  char* W3s = C3e + 2 * X2S_3PLANE;           // [2][32 rows][416 B]: hi / lo of the k3 weights
+  char* Wfs = W3s + 2 * X2S_W3PLANE;          // [2][64 rows][224 B]: hi / lo of the 1x1 weights
+  float* Bts = reinterpret_cast<float*>(Wfs + 2 * X2S_WFPLANE);   // biases (read where they are added: 16 registers a lane)
   float* B3s = Bts + 256;
   float* Bfs = B3s + 32;
+  const char* Zr = reinterpret_cast<const char*>(Bfs + 64);     // 64 zero bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   // transposed conv: wave = (phase rho, half h of the 64 output channels); rows 64 rho + 32 h + 16 nt + li of Wt
   const int rho = wave >> 1, hh = wave & 1;
@@ -223,11 +253,17 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) wt[nt][ks] = x2_wfrag(p.wt + (64 * rho + 32 * hh + 16 * nt + li) * 256 + 32 * ks + 8 * g);
   for (int q = tid; q < 256 + 32 + 64; q += 512) Bts[q] = q < 256 ? p.bt[q] : (q < 288 ? p.b3[q - 256] : p.bf[q - 288]);
-  // k3 conv: wave = (column tile nt3 = wave & 1, row tiles 2 (wave >> 1), +1); weights in registers
+  if (tid < 16) Bfs[64 + tid] = 0.f;
+  // k3 conv: wave = (column tile nt3 = wave & 1, row tiles 2 (wave >> 1), +1); weights hi / lo in LDS (in registers they left the product loops no room to read a step ahead)
   const int nt3 = wave & 1, rg3 = wave >> 1;
-  FragX3 w3[6];
-#pragma unroll
-  for (int ks = 0; ks < 6; ++ks) w3[ks] = x2_wfrag(p.w3 + (16 * nt3 + li) * 192 + 32 * ks + 8 * g);
+  for (int q = tid; q < 32 * 24; q += 512) {
+    const int row = q / 24, ch = q - row * 24;
+    Frag<float> f;
+    frag_load_global(f, p.w3 + row * 192 + 8 * ch);
+    const FragX3 s = split_x3(f);
+    *reinterpret_cast<bf16x8_t*>(W3s + row * X2S_W3S + 16 * ch) = s.hi;
+    *reinterpret_cast<bf16x8_t*>(W3s + X2S_W3PLANE + row * X2S_W3S + 16 * ch) = s.lo;
+  }
   // 1x1: wave = (column tile ntf = wave & 3, row tiles 4 (wave >> 2) .. + 3); weights hi / lo in LDS
   const int ntf = wave & 3, rgf = wave >> 2;
   for (int q = tid; q < 64 * 12; q += 512) {
@@ -236,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
     frag_load_global(f, p.wf + row * 96 + 8 * ch);
     const FragX3 s = split_x3(f);
     *reinterpret_cast<bf16x8_t*>(Wfs + row * X2S_WFS + 16 * ch) = s.hi;
-    *reinterpret_cast<bf16x8_t*>(Wfs + X2S_WPLANE + row * X2S_WFS + 16 * ch) = s.lo;
+    *reinterpret_cast<bf16x8_t*>(Wfs + X2S_WFPLANE + row * X2S_WFS + 16 * ch) = s.lo;
   }
   const int n_out = 4 * p.n;
 
@@ -253,82 +289,138 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
     }
   };
   const int n_tiles = p.B * p.tiles_per_item;
+  XT_DECL;
   __builtin_amdgcn_s_waitcnt(0x0F70);
   if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * X2S_RIN;
     const int ni0 = n0 >= X2S_HALO ? n0 - X2S_HALO : 0;
     const int t_base = 4 * ni0;
+    XT_STAMP(1, 5, 0);
     __syncthreads();
     *reinterpret_cast<u32x4_t*>(Xin + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfh;
     *reinterpret_cast<u32x4_t*>(Xin + X2S_XPLANE + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfl;
     __syncthreads();
+    XT_STAMP(1, 5, 1);
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+    // Every product loop below is an explicit two-stage pipeline -- the LDS reads of step s + 1 are issued, THEN the six MFMAs of
+    // step s (two independent accumulators, interleaved) -- pinned with sched_barrier: left alone, hipcc (at 254 registers) emitted
+    // read -> s_waitcnt 0 -> three dependent MFMAs per step, and tools/x2_trace.py measured 36 % MFMA occupancy in the k3 and 1x1
+    // phases.
     // ---- transposed conv: x1[4 i + rho][32 h + co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*64 + 32 h + co][tap*128 + ci] ----
+    {
+      auto ld = [&](int s_) {
+        const int rt_ = s_ >> 3, ks_ = s_ & 7, src = 16 * rt_ + li - (ks_ >> 2);
+        // xe[-1] = 0 at the start of an item: the address moves to 64 zero bytes (a predicated load became a branch per product)
+        const char* ph = src >= 0 ? Xin + src * X2S_XS + (ks_ & 3) * 64 + 16 * g : Zr + 16 * g;
+        FragX3 f;
+        f.hi = x2_frag16(ph); f.lo = x2_frag16(src >= 0 ? ph + X2S_XPLANE : ph);
+        return f;
+      };
+      FragX3 fa = ld(0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-      const int i = 16 * rt + li;
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int src = i - (ks >> 2);
-        FragX3 fa;
-        if (src >= 0) { fa.hi = x2_frag16(Xin + src * X2S_XS + (ks & 3) * 64 + 16 * g); fa.lo = x2_frag16(Xin + X2S_XPLANE + src * X2S_XS + (ks & 3) * 64 + 16 * g); }
-        else fa = x2_zero();
-        mma16x3(acc[0], wt[0][ks], fa); mma16x3(acc[1], wt[1][ks], fa);
-      }
-      const int orow = 4 * i + rho;
+        for (int ks = 0; ks < 8; ++ks) {
+          FragX3 fn = fa;
+          if (8 * rt + ks + 1 < 16) fn = ld(8 * rt + ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma16x3_2a(acc[0], wt[0][ks], acc[1], wt[1][ks], fa);
+          __builtin_amdgcn_sched_barrier(0);
+          fa = fn;
+        }
+        const int orow = 4 * (16 * rt + li) + rho;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const f32x4_t bt4 = *reinterpret_cast<const f32x4_t*>(Bts + 64 * rho + 32 * hh + 16 * nt + 4 * g);
-        float v[4];
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4_t bt4 = *reinterpret_cast<const f32x4_t*>(Bts + 64 * rho + 32 * hh + 16 * nt + 4 * g);
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[nt][r] + bt4[r];
-        char* dr = X1r + orow * X2S_S1 + (32 * hh + 16 * nt + 4 * g) * 2;
-        x2_store4(dr, dr + X2S_1PLANE, v[0], v[1], v[2], v[3]);
-        char* de = X1e + orow * X2S_S1 + (32 * hh + 16 * nt + 4 * g) * 2;
-        x2_store4(de, de + X2S_1PLANE, x2_elu(v[0]), x2_elu(v[1]), x2_elu(v[2]), x2_elu(v[3]));
-      }
-    }
-    __syncthreads();
-    // ---- c3e[j][16 nt3 ..] = ELU(b3 + conv k3 over ELU(x1)) ----
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const int j = 16 * (2 * rg3 + rr) + li, t = t_base + j;
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) {
-        const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
-        const bool ok = sj >= 0 && sj < X2S_RO;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          FragX3 fa;
-          if (ok) { fa.hi = x2_frag8(X1e + sj * X2S_S1 + 64 * kk + 16 * g); fa.lo = x2_frag8(X1e + X2S_1PLANE + sj * X2S_S1 + 64 * kk + 16 * g); }
-          else fa = x2_zero();
-          mma16x3(acc, w3[2 * tap + kk], fa);
+          for (int r = 0; r < 4; ++r) v[r] = acc[nt][r] + bt4[r];
+          const int off = x2_sw128(orow, 4 * hh + 2 * nt + (g >> 1)) + 8 * (g & 1);           // channels 32 hh + 16 nt + 4 g ..
+          char* dr = X1r + off;
+          x2_store4(dr, dr + X2S_1PLANE, v[0], v[1], v[2], v[3]);
+          char* de = X1e + off;
+          x2_store4(de, de + X2S_1PLANE, x2_elu(v[0]), x2_elu(v[1]), x2_elu(v[2]), x2_elu(v[3]));
         }
       }
-      const f32x4_t b34 = *reinterpret_cast<const f32x4_t*>(B3s + 16 * nt3 + 4 * g);
-      char* dst = C3e + j * X2S_S3 + (16 * nt3 + 4 * g) * 2;
-      x2_store4(dst, dst + X2S_3PLANE, x2_elu(acc[0] + b34[0]), x2_elu(acc[1] + b34[1]), x2_elu(acc[2] + b34[2]), x2_elu(acc[3] + b34[3]));
     }
+    XT_STAMP(1, 5, 2);
     __syncthreads();
+    XT_STAMP(1, 5, 3);
+    // ---- c3e[j][16 nt3 ..] = ELU(b3 + conv k3 over ELU(x1)); the wave's two row tiles are the two accumulators ----
+    {
+      int jj[2], tt[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) { jj[rr] = 16 * (2 * rg3 + rr) + li; tt[rr] = t_base + jj[rr]; }
+      auto ld = [&](int s_, int rr) {
+        const int tap = s_ >> 1, kk = s_ & 1;
+        // rows before the tile belong to the halo rows of a tile that does not start an item: their results are never used, so
+        // the row index is clamped instead of the load being predicated
+        const int v = tt[rr] + tap - 2, sj0 = (v < 0 ? -v : v) - t_base, sj = sj0 < 0 ? 0 : sj0;
+        FragX3 f;
+        const int off = x2_sw128(sj, 4 * kk + g);
+        f.hi = x2_frag16(X1e + off); f.lo = x2_frag16(X1e + X2S_1PLANE + off);
+        return f;
+      };
+      auto ldw = [&](int s_) {
+        FragX3 w;
+        w.hi = x2_frag16(W3s + (16 * nt3 + li) * X2S_W3S + (32 * s_ + 8 * g) * 2);
+        w.lo = x2_frag16(W3s + X2S_W3PLANE + (16 * nt3 + li) * X2S_W3S + (32 * s_ + 8 * g) * 2);
+        return w;
+      };
+      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+      FragX3 wb = ldw(0), f0 = ld(0, 0), f1 = ld(0, 1);
+#pragma unroll
+      for (int s_ = 0; s_ < 6; ++s_) {
+        FragX3 n0 = f0, n1 = f1, wn = wb;
+        if (s_ + 1 < 6) { wn = ldw(s_ + 1); n0 = ld(s_ + 1, 0); n1 = ld(s_ + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma16x3_2b(acc[0], f0, acc[1], f1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = n0; f1 = n1; wb = wn;
+      }
+      const f32x4_t b34 = *reinterpret_cast<const f32x4_t*>(B3s + 16 * nt3 + 4 * g);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        char* dst = C3e + x2_sw64(jj[rr], 2 * nt3 + (g >> 1)) + 8 * (g & 1);
+        x2_store4(dst, dst + X2S_3PLANE, x2_elu(acc[rr][0] + b34[0]), x2_elu(acc[rr][1] + b34[1]), x2_elu(acc[rr][2] + b34[2]), x2_elu(acc[rr][3] + b34[3]));
+      }
+    }
+    XT_STAMP(1, 5, 4);
+    __syncthreads();
+    XT_STAMP(1, 5, 5);
     // ---- out[j][16 ntf ..] = ELU(bf + Wf [c3e[j] (32) | x1[j] (64)]); rows 64 rgf .. 64 rgf + 63; staged over X1e ----
     f32x4_t acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      FragX3 wb;
-      wb.hi = x2_frag16(Wfs + (16 * ntf + li) * X2S_WFS + (32 * ks + 8 * g) * 2);
-      wb.lo = x2_frag16(Wfs + X2S_WPLANE + (16 * ntf + li) * X2S_WFS + (32 * ks + 8 * g) * 2);
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+    {
+      auto ld = [&](int ks, int rt) {
         const int j = 16 * (4 * rgf + rt) + li;
-        FragX3 fa;
-        if (ks == 0) { fa.hi = x2_frag8(C3e + j * X2S_S3 + 16 * g); fa.lo = x2_frag8(C3e + X2S_3PLANE + j * X2S_S3 + 16 * g); }
-        else { fa.hi = x2_frag8(X1r + j * X2S_S1 + 64 * (ks - 1) + 16 * g); fa.lo = x2_frag8(X1r + X2S_1PLANE + j * X2S_S1 + 64 * (ks - 1) + 16 * g); }
-        mma16x3(acc[rt], wb, fa);
+        FragX3 f;
+        if (ks == 0) { const int off = x2_sw64(j, g); f.hi = x2_frag16(C3e + off); f.lo = x2_frag16(C3e + X2S_3PLANE + off); }
+        else { const int off = x2_sw128(j, 4 * (ks - 1) + g); f.hi = x2_frag16(X1r + off); f.lo = x2_frag16(X1r + X2S_1PLANE + off); }
+        return f;
+      };
+      auto ldw = [&](int ks) {
+        FragX3 w;
+        w.hi = x2_frag16(Wfs + (16 * ntf + li) * X2S_WFS + 64 * ks + 16 * g);
+        w.lo = x2_frag16(Wfs + X2S_WFPLANE + (16 * ntf + li) * X2S_WFS + 64 * ks + 16 * g);
+        return w;
+      };
+      FragX3 wb = ldw(0), f0 = ld(0, 0), f1 = ld(0, 1);
+#pragma unroll
+      for (int s_ = 0; s_ < 6; ++s_) {                             // step = (ks = s_ >> 1, row tiles 2 (s_ & 1), + 1)
+        const int ks = s_ >> 1, rp = s_ & 1;
+        FragX3 n0 = f0, n1 = f1, wn = wb;
+        if (s_ + 1 < 6) {
+          n0 = ld((s_ + 1) >> 1, 2 * ((s_ + 1) & 1)); n1 = ld((s_ + 1) >> 1, 2 * ((s_ + 1) & 1) + 1);
+          if (((s_ + 1) >> 1) != ks) wn = ldw((s_ + 1) >> 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma16x3_2b(acc[2 * rp], f0, acc[2 * rp + 1], f1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = n0; f1 = n1; wb = wn;
       }
     }
     // X1e was last read by the k3 conv, which every wave has left (barrier above); the output tile is staged there so that HBM
@@ -337,18 +429,22 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       const int j = 16 * (4 * rgf + rt) + li;
-      char* dst = X1e + j * X2S_S1 + (16 * ntf + 4 * g) * 2;
+      char* dst = X1e + x2_sw128(j, 2 * ntf + (g >> 1)) + 8 * (g & 1);
       x2_store4(dst, dst + X2S_1PLANE, x2_elu(acc[rt][0] + bf4[0]), x2_elu(acc[rt][1] + bf4[1]), x2_elu(acc[rt][2] + bf4[2]), x2_elu(acc[rt][3] + bf4[3]));
     }
+    XT_STAMP(1, 5, 6);
     __syncthreads();
+    XT_STAMP(1, 5, 7);
     const int j_lo = 4 * (n0 - ni0);
     for (int q = tid; q < 4 * X2S_RIN * 16; q += 512) {         // 120 rows x (8 hi + 8 lo chunks)
       const int i = q >> 4, ch = q & 15, t = 4 * n0 + i;
       if (t < n_out) {
         const int pl = ch >> 3, c = ch & 7;
-        *reinterpret_cast<bf16x8_t*>(p.y + ((int64_t)b * n_out + t) * p.ldy + pl * X2S_C + 8 * c) = x2_frag8(X1e + pl * X2S_1PLANE + (j_lo + i) * X2S_S1 + 16 * c);
+        *reinterpret_cast<bf16x8_t*>(p.y + ((int64_t)b * n_out + t) * p.ldy + pl * X2S_C + 8 * c) = x2_frag16(X1e + pl * X2S_1PLANE + x2_sw128(j_lo + i, c));
       }
     }
+    XT_STAMP(1, 5, 8);
+    XT_NEXT;
   }
 }
 
@@ -425,12 +521,14 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
     }
   };
   const int n_tiles = p.B * p.tiles_per_item;
+  XT_DECL;
   __builtin_amdgcn_s_waitcnt(0x0F70);
   if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * X2T_RIN;
     const int ni0 = n0 >= X2T_HALO ? n0 - X2T_HALO : 0;          // first input row held in LDS
     const int t_base = 2 * ni0;                                   // output row of LDS row 0 of X1 / C3e / Oute
+    XT_STAMP(2, 3, 0);
     __syncthreads();                                              // previous tile's LDS reads are done
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -439,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
       *reinterpret_cast<u32x4_t*>(Xin + X2T_XPLANE + (q >> 3) * X2T_XS + 16 * (q & 7)) = pfl[k];
     }
     __syncthreads();
+    XT_STAMP(2, 3, 1);
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- B: transposed conv: x1[2 i + rho][co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*32 + co][tap*64 + ci]; row tile = wave ----
     {
@@ -468,7 +567,9 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
         x2_store4(de, de + X2T_1PLANE, x2_elu(v[0]), x2_elu(v[1]), x2_elu(v[2]), x2_elu(v[3]));
       }
     }
+    XT_STAMP(2, 3, 2);
     __syncthreads();
+    XT_STAMP(2, 3, 3);
     // ---- C: c3e[j] = ELU(b3 + conv k3 over ELU(x1), causal with reflect at the item start) ----
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -486,7 +587,9 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
       char* dst = C3e + j * X2T_S32 + 8 * g;
       x2_store4(dst, dst + X2T_3PLANE, x2_elu(acc[0] + b34[0]), x2_elu(acc[1] + b34[1]), x2_elu(acc[2] + b34[2]), x2_elu(acc[3] + b34[3]));
     }
+    XT_STAMP(2, 3, 4);
     __syncthreads();
+    XT_STAMP(2, 3, 5);
     // ---- D: oute[j] = ELU(bf + Wf [c3e[j] (16) | x1[j] (32)]) ----
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -509,7 +612,9 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
                   x2_elu(acc[nt][3] + bf4[nt][3]));
       }
     }
+    XT_STAMP(2, 3, 6);
     __syncthreads();
+    XT_STAMP(2, 3, 7);
     // ---- E: P[j][tap] = sum_c wfin[tap][c] oute[j][c]  (one product per row tile: D[row = tap][col = row j]) ----
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -520,7 +625,9 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
       mma16x3(acc, wfin, fa);
       if (g < 2) *reinterpret_cast<f32x4_t*>(Ptap + j * 8 + 4 * g) = acc;        // taps 4 g + r
     }
+    XT_STAMP(2, 3, 8);
     __syncthreads();
+    XT_STAMP(2, 3, 9);
     // ---- F: wav[t] = bfin + sum_tap P[reflect(t + tap - 6)][tap]; only this tile's own 112 samples are written ----
     const int j_lo = 2 * (n0 - ni0);
     if (tid < 2 * X2T_RIN) {
@@ -535,6 +642,8 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
         p.wav[(int64_t)b * n_out + t] = s;
       }
     }
+    XT_STAMP(2, 3, 10);
+    XT_NEXT;
   }
 }
 
@@ -592,3 +701,9 @@ int pt_x2_encodec_tail(const pt_encodec_tail_desc* d, hipStream_t s) {
   PT_LAUNCH_CHECK();
   return PT_OK;
 }
+
+#if X2_TRACE
+extern "C" int pt_debug_x2_trace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(x2_trace_buf), sizeof(unsigned long long) * (n < 768 ? n : 768)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -47,6 +47,25 @@ __device__ __forceinline__ void mma16x3(f32x4_t& acc, const FragX3& a, const Fra
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
 }
 
+// Two accumulators at once, products interleaved so that no MFMA reads the accumulator the one before it writes (a dependent
+// 16x16x32 issues ~10 cycles later than an independent one); per accumulator the order of the three terms is mma16x3's.
+__device__ __forceinline__ void mma16x3_2a(f32x4_t& acc0, const FragX3& a0, f32x4_t& acc1, const FragX3& a1, const FragX3& b) {   // two A (weights), one B
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.lo, b.hi, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.lo, b.hi, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.hi, b.lo, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.hi, b.lo, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.hi, b.hi, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.hi, b.hi, acc1, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16x3_2b(f32x4_t& acc0, const FragX3& b0, f32x4_t& acc1, const FragX3& b1, const FragX3& a) {   // one A, two B
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b0.hi, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b1.hi, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b0.lo, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b1.lo, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b0.hi, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b1.hi, acc1, 0, 0, 0);
+}
+
 // pack 8 f32 (lane-local) into a fragment
 __device__ __forceinline__ void frag_from_f32(Frag<bf16_t>& f, const float* x) {
 #pragma unroll
