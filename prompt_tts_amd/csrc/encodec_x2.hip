@@ -158,38 +158,61 @@ __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResPara
     __syncthreads();
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- c3e[j][16 nt3 ..] = ELU(b3 + conv k3 over ELU(x1), causal with reflect at the item start); rows 32 rh .. 32 rh + 31 ----
+    // Product loops as in encodec_stage2_x2_kernel: the reads of step s + 1 are issued before the MFMAs of step s (pinned), two
+    // accumulators interleaved, accumulators start at the bias.
+    {
+      int jj[2], tt[2];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const int j = 16 * (2 * rh + rr) + li, t = t_base + j;
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) {
+      for (int rr = 0; rr < 2; ++rr) { jj[rr] = 16 * (2 * rh + rr) + li; tt[rr] = t_base + jj[rr]; }
+      auto ld = [&](int s_, int rr) {
+        const int tap = s_ >> 2, kk = s_ & 3;
         // rows before the tile belong to the halo rows of a tile that does not start an item: their results are never used, so
         // the row index is clamped instead of the load being predicated (a predicated load became a branch around every product)
-        const int v = t + tap - 2, sj0 = (v < 0 ? -v : v) - t_base, sj = sj0 < 0 ? 0 : sj0;
+        const int v = tt[rr] + tap - 2, sj0 = (v < 0 ? -v : v) - t_base, sj = sj0 < 0 ? 0 : sj0;
+        FragX3 f;
+        f.hi = x2_frag16(X1e + sj * XR_XS + 64 * kk + 16 * g); f.lo = x2_frag16(X1e + XR_XPLANE + sj * XR_XS + 64 * kk + 16 * g);
+        return f;
+      };
+      f32x4_t acc[2] = {(f32x4_t){b34[0], b34[1], b34[2], b34[3]}, (f32x4_t){b34[0], b34[1], b34[2], b34[3]}};
+      FragX3 f0 = ld(0, 0), f1 = ld(0, 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          FragX3 fa;
-          fa.hi = x2_frag16(X1e + sj * XR_XS + 64 * kk + 16 * g); fa.lo = x2_frag16(X1e + XR_XPLANE + sj * XR_XS + 64 * kk + 16 * g);
-          mma16x3(acc, w3[4 * tap + kk], fa);                  // D[row = channel 16 nt3 + 4 g + r][col = row j]
-        }
+      for (int s_ = 0; s_ < 12; ++s_) {
+        FragX3 n0 = f0, n1 = f1;
+        if (s_ + 1 < 12) { n0 = ld(s_ + 1, 0); n1 = ld(s_ + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma16x3_2b(acc[0], f0, acc[1], f1, w3[s_]);             // D[row = channel 16 nt3 + 4 g + r][col = row j]
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = n0; f1 = n1;
       }
-      char* dst = C3e + x2_sw128(j, 2 * nt3 + (g >> 1)) + 8 * (g & 1);
-      x2_store4(dst, dst + XR_3PLANE, x2_elu(acc[0] + b34[0]), x2_elu(acc[1] + b34[1]), x2_elu(acc[2] + b34[2]), x2_elu(acc[3] + b34[3]));
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        char* dst = C3e + x2_sw128(jj[rr], 2 * nt3 + (g >> 1)) + 8 * (g & 1);
+        x2_store4(dst, dst + XR_3PLANE, x2_elu(acc[rr][0]), x2_elu(acc[rr][1]), x2_elu(acc[rr][2]), x2_elu(acc[rr][3]));
+      }
     }
     __syncthreads();
     // ---- out[j][16 wave ..] = ELU(bf + Wf [c3e[j] (64) | x1[j] (128)]) -> LDS (over X1e) ----
     f32x4_t acc[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const int j = 16 * rt + li;
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4_t){bf4[0], bf4[1], bf4[2], bf4[3]};
+    {
+      auto ld = [&](int ks, int rt) {
+        const int j = 16 * rt + li;
+        FragX3 f;
+        if (ks < 2) { const int off = x2_sw128(j, 4 * ks + g); f.hi = x2_frag16(C3e + off); f.lo = x2_frag16(C3e + XR_3PLANE + off); }
+        else { f.hi = x2_frag16(X1r + j * XR_XS + 64 * (ks - 2) + 16 * g); f.lo = x2_frag16(X1r + XR_XPLANE + j * XR_XS + 64 * (ks - 2) + 16 * g); }
+        return f;
+      };
+      FragX3 f0 = ld(0, 0), f1 = ld(0, 1);
 #pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
-        FragX3 fa;
-        if (ks < 2) { const int off = x2_sw128(j, 4 * ks + g); fa.hi = x2_frag16(C3e + off); fa.lo = x2_frag16(C3e + XR_3PLANE + off); }
-        else { fa.hi = x2_frag16(X1r + j * XR_XS + 64 * (ks - 2) + 16 * g); fa.lo = x2_frag16(X1r + XR_XPLANE + j * XR_XS + 64 * (ks - 2) + 16 * g); }
-        mma16x3(acc[rt], wf[ks], fa);
+      for (int s_ = 0; s_ < 12; ++s_) {                            // step = (row tiles 2 (s_ / 6), + 1; ks = s_ % 6)
+        const int rp = s_ / 6, ks = s_ % 6;
+        FragX3 n0 = f0, n1 = f1;
+        if (s_ + 1 < 12) { n0 = ld((s_ + 1) % 6, 2 * ((s_ + 1) / 6)); n1 = ld((s_ + 1) % 6, 2 * ((s_ + 1) / 6) + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma16x3_2b(acc[2 * rp], f0, acc[2 * rp + 1], f1, wf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = n0; f1 = n1;
       }
     }
     // X1e was last read by the k3 conv, which every wave has left (barrier above): the output tile is staged there
@@ -197,16 +220,23 @@ __global__ __launch_bounds__(512, 1) void encodec_res1_x2_kernel(const X2ResPara
     for (int rt = 0; rt < 4; ++rt) {
       const int j = 16 * rt + li;
       char* dst = X1e + j * XR_XS + (16 * wave + 4 * g) * 2;
-      x2_store4(dst, dst + XR_XPLANE, x2_elu(acc[rt][0] + bf4[0]), x2_elu(acc[rt][1] + bf4[1]), x2_elu(acc[rt][2] + bf4[2]), x2_elu(acc[rt][3] + bf4[3]));
+      x2_store4(dst, dst + XR_XPLANE, x2_elu(acc[rt][0]), x2_elu(acc[rt][1]), x2_elu(acc[rt][2]), x2_elu(acc[rt][3]));
     }
     __syncthreads();
     const int j_lo = n0 - t_base;
-    for (int q = tid; q < XR_OWN * 32; q += 512) {             // 62 rows x (16 hi + 16 lo chunks)
-      const int i = q >> 5, ch = q & 31, t = n0 + i;
-      if (t < p.n) {
-        const int pl = ch >> 4, c = ch & 15;
-        *reinterpret_cast<u32x4_t*>(p.y + ((int64_t)b * p.n + t) * p.ldy + pl * XR_C + 8 * c) =
-            *reinterpret_cast<const u32x4_t*>(X1e + pl * XR_XPLANE + (j_lo + i) * XR_XS + 16 * c);
+    {                                                             // 62 rows x (16 hi + 16 lo chunks): four reads, then four stores
+      const int i0 = tid >> 5, ch = tid & 31, pl = ch >> 4, c = ch & 15;
+      bf16_t* yb = p.y + ((int64_t)b * p.n + n0 + i0) * p.ldy + pl * XR_C + 8 * c;
+      u32x4_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 16 * k < XR_OWN ? i0 + 16 * k : XR_OWN - 1;
+        o[k] = *reinterpret_cast<const u32x4_t*>(X1e + pl * XR_XPLANE + (j_lo + i) * XR_XS + 16 * c);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 16 * k;
+        if (i < XR_OWN && n0 + i < p.n) *reinterpret_cast<u32x4_t*>(yb + (int64_t)(16 * k) * p.ldy) = o[k];
       }
     }
   }
@@ -291,16 +321,20 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
   const int n_tiles = p.B * p.tiles_per_item;
   XT_DECL;
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  // The prefetched rows go to LDS at the END of the previous tile, between its last barrier and its output stores: loads and
+  // stores share one vmcnt, the store count of a tile is not a compile-time constant, so a copy placed after the stores waited
+  // for every store's acknowledgement (tools/x2_trace.py: ~500 cycles a tile).  Xin is dead from the transposed conv on.
+  auto fill = [&]() {
+    *reinterpret_cast<u32x4_t*>(Xin + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfh;
+    *reinterpret_cast<u32x4_t*>(Xin + X2S_XPLANE + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfl;
+  };
+  if ((int)blockIdx.x < n_tiles) { fetch(blockIdx.x); fill(); }
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * X2S_RIN;
     const int ni0 = n0 >= X2S_HALO ? n0 - X2S_HALO : 0;
     const int t_base = 4 * ni0;
     XT_STAMP(1, 5, 0);
-    __syncthreads();
-    *reinterpret_cast<u32x4_t*>(Xin + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfh;
-    *reinterpret_cast<u32x4_t*>(Xin + X2S_XPLANE + (tid >> 4) * X2S_XS + 16 * (tid & 15)) = pfl;
-    __syncthreads();
+    __syncthreads();                                              // Xin is filled; the previous tile's staged output has been read
     XT_STAMP(1, 5, 1);
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // Every product loop below is an explicit two-stage pipeline -- the LDS reads of step s + 1 are issued, THEN the six MFMAs of
@@ -320,7 +354,11 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
       FragX3 fa = ld(0);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        // accumulators start at the bias: read from LDS here, under the first fragments' latency (read in the epilogue, each bias
+        // fetch was an exposed LDS round trip: tools/x2_trace.py)
+        f32x4_t acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = *reinterpret_cast<const f32x4_t*>(Bts + 64 * rho + 32 * hh + 16 * nt + 4 * g);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           FragX3 fn = fa;
@@ -330,19 +368,25 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
           __builtin_amdgcn_sched_barrier(0);
           fa = fn;
         }
+#if X2_TRACE
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]));     // the stamp waits for the block's last MFMAs
+        XT_STAMP(1, 5, 9 + 2 * rt);
+#endif
         const int orow = 4 * (16 * rt + li) + rho;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const f32x4_t bt4 = *reinterpret_cast<const f32x4_t*>(Bts + 64 * rho + 32 * hh + 16 * nt + 4 * g);
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[nt][r] + bt4[r];
+          for (int r = 0; r < 4; ++r) v[r] = acc[nt][r];
           const int off = x2_sw128(orow, 4 * hh + 2 * nt + (g >> 1)) + 8 * (g & 1);           // channels 32 hh + 16 nt + 4 g ..
           char* dr = X1r + off;
           x2_store4(dr, dr + X2S_1PLANE, v[0], v[1], v[2], v[3]);
           char* de = X1e + off;
           x2_store4(de, de + X2S_1PLANE, x2_elu(v[0]), x2_elu(v[1]), x2_elu(v[2]), x2_elu(v[3]));
         }
+#if X2_TRACE
+        if (rt == 0) XT_STAMP(1, 5, 10);
+#endif
       }
     }
     XT_STAMP(1, 5, 2);
@@ -369,7 +413,8 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
         w.lo = x2_frag16(W3s + X2S_W3PLANE + (16 * nt3 + li) * X2S_W3S + (32 * s_ + 8 * g) * 2);
         return w;
       };
-      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+      f32x4_t acc[2];                                             // start at the bias (see the transposed conv)
+      acc[0] = *reinterpret_cast<const f32x4_t*>(B3s + 16 * nt3 + 4 * g); acc[1] = acc[0];
       FragX3 wb = ldw(0), f0 = ld(0, 0), f1 = ld(0, 1);
 #pragma unroll
       for (int s_ = 0; s_ < 6; ++s_) {
@@ -380,20 +425,20 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
         __builtin_amdgcn_sched_barrier(0);
         f0 = n0; f1 = n1; wb = wn;
       }
-      const f32x4_t b34 = *reinterpret_cast<const f32x4_t*>(B3s + 16 * nt3 + 4 * g);
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         char* dst = C3e + x2_sw64(jj[rr], 2 * nt3 + (g >> 1)) + 8 * (g & 1);
-        x2_store4(dst, dst + X2S_3PLANE, x2_elu(acc[rr][0] + b34[0]), x2_elu(acc[rr][1] + b34[1]), x2_elu(acc[rr][2] + b34[2]), x2_elu(acc[rr][3] + b34[3]));
+        x2_store4(dst, dst + X2S_3PLANE, x2_elu(acc[rr][0]), x2_elu(acc[rr][1]), x2_elu(acc[rr][2]), x2_elu(acc[rr][3]));
       }
     }
     XT_STAMP(1, 5, 4);
     __syncthreads();
     XT_STAMP(1, 5, 5);
     // ---- out[j][16 ntf ..] = ELU(bf + Wf [c3e[j] (32) | x1[j] (64)]); rows 64 rgf .. 64 rgf + 63; staged over X1e ----
-    f32x4_t acc[4];
+    f32x4_t acc[4];                                               // start at the bias (see the transposed conv)
+    acc[0] = *reinterpret_cast<const f32x4_t*>(Bfs + 16 * ntf + 4 * g);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int rt = 1; rt < 4; ++rt) acc[rt] = acc[0];
     {
       auto ld = [&](int ks, int rt) {
         const int j = 16 * (4 * rgf + rt) + li;
@@ -425,22 +470,37 @@ __global__ __launch_bounds__(512, 1) void encodec_stage2_x2_kernel(const X2Stage
     }
     // X1e was last read by the k3 conv, which every wave has left (barrier above); the output tile is staged there so that HBM
     // sees whole 128-byte plane rows
-    const f32x4_t bf4 = *reinterpret_cast<const f32x4_t*>(Bfs + 16 * ntf + 4 * g);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       const int j = 16 * (4 * rgf + rt) + li;
       char* dst = X1e + x2_sw128(j, 2 * ntf + (g >> 1)) + 8 * (g & 1);
-      x2_store4(dst, dst + X2S_1PLANE, x2_elu(acc[rt][0] + bf4[0]), x2_elu(acc[rt][1] + bf4[1]), x2_elu(acc[rt][2] + bf4[2]), x2_elu(acc[rt][3] + bf4[3]));
+      x2_store4(dst, dst + X2S_1PLANE, x2_elu(acc[rt][0]), x2_elu(acc[rt][1]), x2_elu(acc[rt][2]), x2_elu(acc[rt][3]));
     }
     XT_STAMP(1, 5, 6);
     __syncthreads();
     XT_STAMP(1, 5, 7);
     const int j_lo = 4 * (n0 - ni0);
-    for (int q = tid; q < 4 * X2S_RIN * 16; q += 512) {         // 120 rows x (8 hi + 8 lo chunks)
-      const int i = q >> 4, ch = q & 15, t = 4 * n0 + i;
-      if (t < n_out) {
-        const int pl = ch >> 3, c = ch & 7;
-        *reinterpret_cast<bf16x8_t*>(p.y + ((int64_t)b * n_out + t) * p.ldy + pl * X2S_C + 8 * c) = x2_frag16(X1e + pl * X2S_1PLANE + x2_sw128(j_lo + i, c));
+#if X2_TRACE
+    XT_STAMP(1, 5, 12);
+#endif
+    if (tile + (int)gridDim.x < n_tiles) fill();                 // the next tile's rows (fetched at the top of this one)
+#if X2_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    XT_STAMP(1, 5, 13);
+#endif
+    {                                                             // 120 rows x (8 hi + 8 lo chunks): four reads, then four stores
+      const int i0 = tid >> 4, ch = tid & 15, pl = ch >> 3, c = ch & 7;
+      bf16_t* yb = p.y + ((int64_t)b * n_out + 4 * n0 + i0) * p.ldy + pl * X2S_C + 8 * c;
+      bf16x8_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 32 * k < 4 * X2S_RIN ? i0 + 32 * k : 4 * X2S_RIN - 1;
+        o[k] = x2_frag16(X1e + pl * X2S_1PLANE + x2_sw128(j_lo + i, c));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 32 * k;
+        if (i < 4 * X2S_RIN && 4 * n0 + i < n_out) *reinterpret_cast<bf16x8_t*>(yb + (int64_t)(32 * k) * p.ldy) = o[k];
       }
     }
     XT_STAMP(1, 5, 8);
@@ -469,17 +529,18 @@ struct X2TailParams {
 };
 
 __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * X2T_XPLANE + 4 * X2T_1PLANE + 2 * X2T_3PLANE + 2 * X2T_WPLANE + 256];
+  __shared__ __attribute__((aligned(16))) char smem[2 * X2T_XPLANE + 4 * X2T_1PLANE + 2 * X2T_3PLANE + 2 * X2T_WPLANE + 256 + 64 + 2048];
   char* Xin = smem;                           // [2][64][144]
   char* X1r = Xin + 2 * X2T_XPLANE;           // [2][128][72]
   char* X1e = X1r + 2 * X2T_1PLANE;           // [2][128][72]
   char* C3e = X1e + 2 * X2T_1PLANE;           // [2][128][40]
   char* W3s = C3e + 2 * X2T_3PLANE;           // [2][16][208]
   float* Bts = reinterpret_cast<float*>(W3s + 2 * X2T_WPLANE);
+  char* Wfin = reinterpret_cast<char*>(Bts + 80);   // [hi | lo][64 lanes][16 B]: the final conv's A fragment (after 64 biases + 64 zero bytes)
   char* Oute = Xin;                           // [2][128][72], written in phase D (Xin is dead after phase B)
   float* Ptap = reinterpret_cast<float*>(C3e);   // [128][8] f32, written in phase E (C3e is dead after phase D)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
-  FragX3 wt[4][4], wf[2][2], wfin;
+  FragX3 wt[4][4], wf[2][2];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -489,7 +550,13 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) wf[nt][ks] = x2_wfrag(p.wf + (16 * nt + li) * 64 + 32 * ks + 8 * g);
   // final conv as ONE product per row tile: A row = tap (7 of 16 rows), K = the 32 channels
-  if (li < 7) wfin = x2_wfrag(p.wfin + 32 * li + 8 * g); else wfin = x2_zero();
+  // (its weights, used once a tile, wait in LDS as hi / lo fragments in lane order: 8 registers fewer held through every phase)
+  if (tid < 64) {
+    FragX3 w = x2_zero();
+    if (li < 7) w = x2_wfrag(p.wfin + 32 * li + 8 * g);
+    *reinterpret_cast<bf16x8_t*>(Wfin + 16 * tid) = w.hi;
+    *reinterpret_cast<bf16x8_t*>(Wfin + 1024 + 16 * tid) = w.lo;
+  }
   for (int q = tid; q < 16 * 12; q += 256) {
     const int row = q / 12, ch = q - row * 12;
     Frag<float> f;
@@ -499,6 +566,8 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
     *reinterpret_cast<bf16x8_t*>(W3s + X2T_WPLANE + row * X2T_W3S + 16 * ch) = s.lo;
   }
   if (tid < 64) Bts[tid] = p.bt[tid];
+  const char* Zr = reinterpret_cast<const char*>(Bts + 64);     // 64 zero bytes
+  if (tid < 16) Bts[64 + tid] = 0.f;
   float b34[4], bf4[2][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { b34[r] = p.b3[4 * g + r]; bf4[0][r] = p.bf[4 * g + r]; bf4[1][r] = p.bf[16 + 4 * g + r]; }
@@ -523,44 +592,46 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
   const int n_tiles = p.B * p.tiles_per_item;
   XT_DECL;
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * X2T_RIN;
-    const int ni0 = n0 >= X2T_HALO ? n0 - X2T_HALO : 0;          // first input row held in LDS
-    const int t_base = 2 * ni0;                                   // output row of LDS row 0 of X1 / C3e / Oute
-    XT_STAMP(2, 3, 0);
-    __syncthreads();                                              // previous tile's LDS reads are done
+  // the prefetched rows go to LDS before the previous tile's waveform stores (see encodec_stage2_x2_kernel): Xin = Oute is dead
+  // once phase E has been left
+  auto fill = [&]() {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int q = tid + 256 * k;
       *reinterpret_cast<u32x4_t*>(Xin + (q >> 3) * X2T_XS + 16 * (q & 7)) = pfh[k];
       *reinterpret_cast<u32x4_t*>(Xin + X2T_XPLANE + (q >> 3) * X2T_XS + 16 * (q & 7)) = pfl[k];
     }
-    __syncthreads();
+  };
+  if ((int)blockIdx.x < n_tiles) { fetch(blockIdx.x); fill(); }
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / p.tiles_per_item, n0 = (tile - b * p.tiles_per_item) * X2T_RIN;
+    const int ni0 = n0 >= X2T_HALO ? n0 - X2T_HALO : 0;          // first input row held in LDS
+    const int t_base = 2 * ni0;                                   // output row of LDS row 0 of X1 / C3e / Oute
+    XT_STAMP(2, 3, 0);
+    __syncthreads();                                              // Xin is filled; the previous tile's tap products have been read
     XT_STAMP(2, 3, 1);
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
     // ---- B: transposed conv: x1[2 i + rho][co] = bt + sum_tap sum_ci xe[i - tap][ci] Wt[rho*32 + co][tap*64 + ci]; row tile = wave ----
     {
       f32x4_t acc[4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4_t*>(Bts + 16 * nt + 4 * g);     // start at the bias
       const int i = 16 * wave + li;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int src = i - (ks >> 1);
         FragX3 fa;
-        if (src >= 0) { fa.hi = x2_frag16(Xin + src * X2T_XS + (ks & 1) * 64 + 16 * g); fa.lo = x2_frag16(Xin + X2T_XPLANE + src * X2T_XS + (ks & 1) * 64 + 16 * g); }
-        else fa = x2_zero();
+        const char* ph = src >= 0 ? Xin + src * X2T_XS + (ks & 1) * 64 + 16 * g : Zr + 16 * g;     // xe[-1] = 0: 64 zero bytes
+        fa.hi = x2_frag16(ph); fa.lo = x2_frag16(src >= 0 ? ph + X2T_XPLANE : ph);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) mma16x3(acc[nt], wt[nt][ks], fa);          // D[row = out column][col = input row]
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {                                            // columns 16 nt + 4 g + r: rho = nt >> 1
         const int orow = 2 * i + (nt >> 1), co = 16 * (nt & 1) + 4 * g;
-        const f32x4_t bt4 = *reinterpret_cast<const f32x4_t*>(Bts + 16 * nt + 4 * g);
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[nt][r] + bt4[r];
+        for (int r = 0; r < 4; ++r) v[r] = acc[nt][r];
         char* dr = X1r + orow * X2T_S64 + co * 2;
         x2_store4(dr, dr + X2T_1PLANE, v[0], v[1], v[2], v[3]);
         char* de = X1e + orow * X2T_S64 + co * 2;
@@ -573,19 +644,18 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
     // ---- C: c3e[j] = ELU(b3 + conv k3 over ELU(x1), causal with reflect at the item start) ----
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      f32x4_t acc = (f32x4_t){b34[0], b34[1], b34[2], b34[3]};
       const int j = 16 * (wave + 4 * rr) + li, t = t_base + j;
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
-        const int v = t + tap - 2, sj = (v < 0 ? -v : v) - t_base;
+        const int v = t + tap - 2, sj0 = (v < 0 ? -v : v) - t_base, sj = sj0 < 0 ? 0 : sj0;     // clamped: see encodec_res1_x2_kernel
         FragX3 fa, wb;
-        if (sj >= 0 && sj < X2T_RO) { fa.hi = x2_frag8(X1e + sj * X2T_S64 + 16 * g); fa.lo = x2_frag8(X1e + X2T_1PLANE + sj * X2T_S64 + 16 * g); }
-        else fa = x2_zero();
+        fa.hi = x2_frag8(X1e + sj * X2T_S64 + 16 * g); fa.lo = x2_frag8(X1e + X2T_1PLANE + sj * X2T_S64 + 16 * g);
         wb.hi = x2_frag16(W3s + li * X2T_W3S + 64 * tap + 16 * g); wb.lo = x2_frag16(W3s + X2T_WPLANE + li * X2T_W3S + 64 * tap + 16 * g);
         mma16x3(acc, wb, fa);
       }
       char* dst = C3e + j * X2T_S32 + 8 * g;
-      x2_store4(dst, dst + X2T_3PLANE, x2_elu(acc[0] + b34[0]), x2_elu(acc[1] + b34[1]), x2_elu(acc[2] + b34[2]), x2_elu(acc[3] + b34[3]));
+      x2_store4(dst, dst + X2T_3PLANE, x2_elu(acc[0]), x2_elu(acc[1]), x2_elu(acc[2]), x2_elu(acc[3]));
     }
     XT_STAMP(2, 3, 4);
     __syncthreads();
@@ -593,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
     // ---- D: oute[j] = ELU(bf + Wf [c3e[j] (16) | x1[j] (32)]) ----
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+      f32x4_t acc[2] = {(f32x4_t){bf4[0][0], bf4[0][1], bf4[0][2], bf4[0][3]}, (f32x4_t){bf4[1][0], bf4[1][1], bf4[1][2], bf4[1][3]}};
       const int j = 16 * (wave + 4 * rr) + li;
       FragX3 f0, f1;
       if (g < 2) {                                                                // k 0..15 = c3e | 16..31 = x1[0..15]
@@ -608,21 +678,22 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         char* dst = Oute + j * X2T_S64 + (16 * nt + 4 * g) * 2;
-        x2_store4(dst, dst + X2T_1PLANE, x2_elu(acc[nt][0] + bf4[nt][0]), x2_elu(acc[nt][1] + bf4[nt][1]), x2_elu(acc[nt][2] + bf4[nt][2]),
-                  x2_elu(acc[nt][3] + bf4[nt][3]));
+        x2_store4(dst, dst + X2T_1PLANE, x2_elu(acc[nt][0]), x2_elu(acc[nt][1]), x2_elu(acc[nt][2]), x2_elu(acc[nt][3]));
       }
     }
     XT_STAMP(2, 3, 6);
     __syncthreads();
     XT_STAMP(2, 3, 7);
     // ---- E: P[j][tap] = sum_c wfin[tap][c] oute[j][c]  (one product per row tile: D[row = tap][col = row j]) ----
+    FragX3 wfe;
+    wfe.hi = x2_frag16(Wfin + 16 * lane); wfe.lo = x2_frag16(Wfin + 1024 + 16 * lane);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const int j = 16 * (wave + 4 * rr) + li;
       FragX3 fa;
       fa.hi = x2_frag8(Oute + j * X2T_S64 + 16 * g); fa.lo = x2_frag8(Oute + X2T_1PLANE + j * X2T_S64 + 16 * g);
-      mma16x3(acc, wfin, fa);
+      mma16x3(acc, wfe, fa);
       if (g < 2) *reinterpret_cast<f32x4_t*>(Ptap + j * 8 + 4 * g) = acc;        // taps 4 g + r
     }
     XT_STAMP(2, 3, 8);
@@ -630,6 +701,7 @@ __global__ __launch_bounds__(256, 2) void encodec_tail_x2_kernel(const X2TailPar
     XT_STAMP(2, 3, 9);
     // ---- F: wav[t] = bfin + sum_tap P[reflect(t + tap - 6)][tap]; only this tile's own 112 samples are written ----
     const int j_lo = 2 * (n0 - ni0);
+    if (tile + (int)gridDim.x < n_tiles) fill();
     if (tid < 2 * X2T_RIN) {
       const int j = j_lo + tid, t = t_base + j;
       if (t < n_out) {

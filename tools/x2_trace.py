@@ -26,8 +26,8 @@ buf = (C.c_ulonglong * 768)()
 assert lib.pt_debug_x2_trace(buf, 768) == 0
 st = list(buf)
 phases = {
-    1: ("stage2", ["bar+fill+bar", "tconv", "bar", "k3", "bar", "1x1+stage", "bar", "store", "to top"]),
-    2: ("tail", ["bar+fill+bar", "B tconv", "bar", "C k3", "bar", "D 1x1", "bar", "E final", "bar", "F sum+store", "to top"]),
+    1: ("stage2", ["top barrier", "tconv", "bar", "k3", "bar", "1x1+stage", "bar", "fill+store", "to top"]),
+    2: ("tail", ["top barrier", "B tconv", "bar", "C k3", "bar", "D 1x1", "bar", "E final", "bar", "F fill+sum+store", "to top"]),
 }
 for k, (name, names) in phases.items():
     for w in range(2):
@@ -38,3 +38,11 @@ for k, (name, names) in phases.items():
             d = [s[i + 1] - s[i] for i in range(len(names) - 1)] + [nxt - s[len(names) - 1]]
             tot = [a + b for a, b in zip(tot, d)]; n += 1; whole += nxt - s[0]
         print(f"{name} wave {'0' if w == 0 else 'other'}: " + "  ".join(f"{nm} {x / n:6.0f}" for nm, x in zip(names, tot)) + f"   tile {whole / n:.0f} cycles")
+        if k == 1:      # inside the transposed conv: MFMAs of row tile 0 done (9), its epilogue issued (10), MFMAs of row tile 1 done (11)
+            sub = [0, 0, 0, 0]
+            for it in range(2, 7):
+                s = st[((k * 2 + w) * 8 + it) * 16:((k * 2 + w) * 8 + it) * 16 + 16]
+                sub = [a + b for a, b in zip(sub, [s[9] - s[1], s[10] - s[9], s[11] - s[10], s[2] - s[11]])]
+            print("    tconv: " + "  ".join(f"{nm} {x / 5:6.0f}" for nm, x in zip(["products 0", "epilogue 0", "products 1", "epilogue 1"], sub)))
+            fill = sum(st[((k * 2 + w) * 8 + it) * 16 + 13] - st[((k * 2 + w) * 8 + it) * 16 + 12] for it in range(2, 7)) / 5
+            print(f"    fill (wait for the prefetched rows + LDS writes) {fill:.0f}")
