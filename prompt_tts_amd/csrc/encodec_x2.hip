@@ -12,8 +12,8 @@
 // input rows prefetched into registers under the current tile's phases), re-cut for twice the bytes per element:
 //   res1   (128 ch, 600 Hz -> 3 kHz stage's residual block): 8 waves, 62 + 2 rows, k3 / 1x1 weights in registers (144 per lane)
 //   stage2 (3 kHz -> 12 kHz: transposed conv k8 s4 128 -> 64 + residual block): 8 waves, 30 + 2 input rows; wave = (phase, half
-//          of the output channels) of the transposed conv with its 32 hi / lo fragments in registers, k3 weights in registers,
-//          1x1 weights in LDS
+//          of the output channels) of the transposed conv with its 32 hi / lo fragments in registers, k3 and 1x1 weights as
+//          hi / lo fragments in LDS
 //   tail   (12 -> 24 kHz: transposed conv k4 s2 64 -> 32 + residual block + final conv k7 32 -> 1): 4 waves, 56 + 8 input rows,
 //          two workgroups per CU; the final conv is ONE MFMA per 16 samples (P[j][tap] = w[tap] . oute[j], then seven adds along
 //          the diagonal) instead of seven with fifteen idle output rows each.
