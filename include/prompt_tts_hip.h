@@ -133,8 +133,9 @@ typedef struct pt_gemm_desc {
 /* dtype PT_BF16X2 (forward GEMMs of f32-class inference; Encodec decode at the reference's fp32 precision): K, N, cin, c_split
  * count LOGICAL elements; every operand row holds its hi plane followed by its lo plane -- A: PT_V_PLAIN [M][>= 2K] (lo at + K),
  * PT_V_CONCAT (p: lo at + c_split, p2: lo at + K - c_split), PT_V_CONV (rows of [cin hi | cin lo]); B: PT_V_PLAIN [N][>= 2K];
- * the kernel is the bf16 GEMM over 3 K columns (A copies {hi, hi, lo}, B copies {hi, lo, hi}).  Outputs: PT_OUT_T = plane rows
- * (ldc >= 2N, see x2_block), PT_OUT_F32 = plain f32.  bias / act 0-1 / C2 + act2; no residuals, transposes or split-K. */
+ * K, cin and c_split multiples of 32, N of 8 (PT_ERR_ARG otherwise): a k-tile of the kernel carries the hi AND the lo plane of 32
+ * logical columns of both operands and issues a_hi w_lo + a_lo w_hi + a_hi w_hi per fragment pair.  Outputs: PT_OUT_T = plane
+ * rows (ldc >= 2N, see x2_block), PT_OUT_F32 = plain f32.  bias / act 0-1 / C2 + act2; no residuals, transposes or split-K. */
 int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream);
 
 /* Grouped weight gradients (bf16): up to 8 GEMMs dW_i (+)= alpha_i dY_i^T X_i in ONE launch + one fold launch.

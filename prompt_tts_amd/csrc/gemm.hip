@@ -43,10 +43,14 @@ struct VOp {
   int64_t step;                // bytes per k-tile inside a segment
   int edge_slow;               // also recompute at positions 1 and seg_kt-1 of a segment (conv rows at batch-item edges)
   int64_t rows, cols;   // logical extent of the virtual matrix
-  // PT_BF16X2 (split storage: a row of C f32-class elements is [C hi | C lo] bf16): the reduction runs over THREE copies of the
-  // logical K columns -- krep = K, cols = 3 K -- and copy s reads plane (pmap >> s) & 1 of the row: activations {hi, hi, lo},
-  // weights {hi, lo, hi}, so that a plain bf16 GEMM over 3 K sums a_hi w_hi + a_hi w_lo + a_lo w_hi (mma.h: the bf16 x 3 product)
-  // with no conversion in its loop.  plane1 / plane2 = element offset of the lo plane in rows of p / p2.  krep = 0: plain storage.
+  // PT_BF16X2 (split storage: a row of C f32-class elements is [C hi | C lo] bf16): the virtual matrix has 2 K columns, k-tile t
+  // (64 columns = one 128-byte row of the LDS image) = [hi of logical columns 32 t .. 32 t + 31 | lo of the same columns], so that
+  // one k-tile carries both planes of 32 logical columns and the loop issues the bf16 x 3 product (mma.h: a_hi w_lo + a_lo w_hi +
+  // a_hi w_hi) from four fragment reads, with no conversion.  Round 4's first form ran a plain bf16 GEMM over THREE plane copies
+  // of K ({hi, hi, lo} against {hi, lo, hi}): the same products, but a_hi and w_hi were staged twice -- and staging, not the
+  // MFMAs, bounds these GEMMs (tools/decode_probe.py on the ablation builds: N = 640, K = 512: 1.69 ms, 0.93 without the
+  // staging loads, 1.16 without the MFMAs).  plane1 / plane2 = element offset of the lo plane in rows of p / p2.  krep = K > 0
+  // marks a plane operand, 0 plain storage.
   int krep, plane1, plane2, pmap;      // (32-bit: eight GemmParams must fit the 4 KiB kernel-argument segment of pt_wgrad_group)
 };
 
@@ -116,10 +120,9 @@ __device__ __forceinline__ const char* vaddr(const VOp& op, int64_t row, int64_t
   if (row >= op.rows || col >= op.cols) return zero;
   const T* ptr;
   int64_t plane = 0;                         // PT_BF16X2: 1 = this copy of the K columns reads the lo plane
-  if (X2 && KC != 2 && op.krep > 0) {
-    const int sidx = col >= 2 * (int64_t)op.krep ? 2 : (col >= op.krep ? 1 : 0);
-    col -= (int64_t)sidx * op.krep;
-    plane = (op.pmap >> sidx) & 1;
+  if (X2 && KC != 2 && op.krep > 0) {       // virtual column -> (plane, logical column)
+    plane = (col >> 5) & 1;
+    col = ((col >> 6) << 5) | (col & 31);
   }
   if (KC == 0) {
     ptr = (op.kind == PT_V_PLAIN || col < op.c_split)
@@ -786,6 +789,26 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
         return;
       }
     }
+    if constexpr (X2) {                                      // k-tile = [32 hi | 32 lo] of both operands: one bf16 x 3 step
+      if (NKS > 0) {
+        FragX3 xb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Frag<T> h, l;
+          frag_load_k(h, sb, wn * 64 + 16 * j + li, 8 * g); frag_load_k(l, sb, wn * 64 + 16 * j + li, 32 + 8 * g);
+          xb[j].hi = h.v; xb[j].lo = l.v;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          Frag<T> h, l;
+          frag_load_k(h, sa, wm * WM + 16 * i + li, 8 * g); frag_load_k(l, sa, wm * WM + 16 * i + li, 32 + 8 * g);
+          FragX3 xa; xa.hi = h.v; xa.lo = l.v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma16x3(acc[i][j], xb[j], xa);      // D[row = n][col = m]
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       Frag<T> fa[MI], fb[4];
@@ -1255,9 +1278,9 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const FoldGroup g) {
 VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es, int x2_map = 0) {
   VOp v;
   v.krep = 0; v.plane1 = v.plane2 = 0; v.pmap = 0;
-  const int64_t K1 = x2_map ? cols / 3 : cols;                 // logical columns of one copy
+  const int64_t K1 = x2_map ? cols / 2 : cols;                 // logical columns
   if (x2_map) {
-    v.krep = (int)K1; v.pmap = x2_map;
+    v.krep = (int)K1; v.pmap = 0;
     if (o.kind == PT_V_CONV) v.plane1 = o.cin;
     else if (o.kind == PT_V_CONCAT) { v.plane1 = (int)o.c_split; v.plane2 = (int)(K1 - o.c_split); }
     else v.plane1 = (int)K1;
@@ -1277,16 +1300,10 @@ VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es, int x2_map
     if (o.kind == PT_V_PLAIN) v.seg_kt = 1 << 30;
     else if (o.kind == PT_V_CONCAT) v.seg_kt = (o.c_split % bk == 0) ? (int)(o.c_split / bk) : 1;
     else if (o.kind == PT_V_CONV) v.seg_kt = (v.cin % bk == 0) ? v.cin / bk : 1;
-    if (x2_map) {
-      // a copy boundary (every K1 columns) must fall on a segment boundary: segments are counted from column 0 in units of seg_kt
-      // k-tiles, so seg_kt bk has to divide K1 (and, for a concat, c_split: the gcd of the two)
-      if (K1 % bk != 0) v.seg_kt = 1;
-      else if (o.kind == PT_V_PLAIN) v.seg_kt = (int)(K1 / bk);
-      else if (o.kind == PT_V_CONCAT && v.seg_kt > 1) {
-        int64_t a = K1 / bk, b = v.seg_kt;
-        while (b) { const int64_t t = a % b; a = b; b = t; }
-        v.seg_kt = (int)a;
-      }
+    if (x2_map) {       // a k-tile advances 32 logical columns in both planes (build_params: K, cin, c_split are multiples of 32)
+      v.step = 32 * es;
+      if (o.kind == PT_V_CONCAT) v.seg_kt = (int)(o.c_split / 32);
+      else if (o.kind == PT_V_CONV) v.seg_kt = v.cin / 32;
     }
   } else {                                      // reduction along rows
     if (o.kind == PT_V_PLAIN) { v.seg_kt = 1 << 30; v.step = (int64_t)bk * o.ld * es; }
@@ -1338,7 +1355,7 @@ int launch_cfg(GemmParams p, hipStream_t s) {
 // Tile choice.  PT_GEMM_TILE=128|256|512|8 (= 128x128 | 256x128 | 256x256 two-stage | 256x256 eight-phase) forces one
 // configuration for A/B probing (tools/gemm_probe.py); PT_GEMM_8P_MASK selects which GEMM classes may use the eight-phase
 // kernel (bit 0 forward plain, 1 dgrad plain, 2 conv forward, 3 conv dgrad, 4 wgrad).
-inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
+inline int pick_tile(const GemmParams& p, int cls, bool bf16, bool x2 = false) {
   static const int forced = pt_env_int("PT_GEMM_TILE", 0), mask = pt_env_int("PT_GEMM_8P_MASK", 0x0f),
                    min8pk = pt_env_int("PT_GEMM_8P_MIN_K", 1536);
   if (forced == 128 || forced == 256 || forced == 512 || forced == 8) return forced;
@@ -1347,7 +1364,8 @@ inline int pick_tile(const GemmParams& p, int cls, bool bf16) {
     // a last column tile that is at most half full and a sixth or more of the tile columns (the Encodec decoder's N = 128 and
     // N = 640 transposed-conv GEMMs): 256 x 128 tiles waste nothing (0.353 -> 0.204 ms and 0.650 -> 0.606 ms, tools/decode_probe.py)
     const int64_t rem = p.N % 256, cols = (p.N + 255) / 256 * 256;
-    if (rem > 0 && rem <= 128 && 6 * (256 - rem) >= cols) return 256;
+    // (plane operands: 128 x 128, two workgroups per CU whose staging overlaps -- N = 640: 1.40 -> 1.32 ms, N = 128: 0.44 -> 0.41)
+    if (rem > 0 && rem <= 128 && 6 * (256 - rem) >= cols) return x2 ? 128 : 256;
     return p.K >= min8pk ? 8 : 512;
   }
   return 128;
@@ -1366,9 +1384,10 @@ int launch_8p(GemmParams p, hipStream_t s) {
 template <typename T, bool TA, bool TB, bool ATOMIC, int KA, int KB, bool X2 = false>
 int launch(const GemmParams& p, hipStream_t s) {
   constexpr int cls = ATOMIC ? 4 : (!TB ? (KA == 0 ? 0 : 2) : (KA == 0 ? 1 : 3));
-  int tile = pick_tile(p, cls, sizeof(T) == 2);
+  int tile = pick_tile(p, cls, sizeof(T) == 2, X2);
   if (p.arow_sum && tile != 128) tile = 128;            // the fused bias gradient lives in the two-stage 128 x 128 kernel
-  if constexpr (sizeof(T) == 2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB, X2>(p, s); }
+  if constexpr (X2) { if (tile == 8) tile = 512; }      // plane operands: the two-stage kernels carry the bf16 x 3 k-tile
+  if constexpr (sizeof(T) == 2 && !X2) { if (tile == 8) return launch_8p<TA, TB, ATOMIC, KA, KB, X2>(p, s); }
   switch (tile) {
     case 512: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 256, X2>(p, s);
     case 256: return launch_cfg<T, TA, TB, ATOMIC, KA, KB, 256, 128, X2>(p, s);
@@ -1414,9 +1433,10 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
   const bool x2 = dtype == PT_BF16X2;
   if (x2) {       // forward GEMMs of f32-class inference only: K-contiguous operands, store epilogue, bias / ELU, one or two outputs
     if (operand_es != 0 || d->A.trans || d->B.trans || d->out_kind == PT_OUT_F32_ATOMIC || d->split_k != 1 || d->residual || d->residual2 ||
-        d->row_bias || d->act > 1 || d->B.kind != PT_V_PLAIN || d->A.kind == PT_V_WFLIP || d->K % 8 != 0 || d->N % 8 != 0 || 3 * d->K >= (1ll << 31))
+        d->row_bias || d->act > 1 || d->B.kind != PT_V_PLAIN || d->A.kind == PT_V_WFLIP || d->K % 32 != 0 || d->N % 8 != 0 || 2 * d->K >= (1ll << 31))
       return PT_ERR_ARG;
-    if (d->A.kind == PT_V_CONCAT && (d->A.c_split <= 0 || d->A.c_split >= d->K)) return PT_ERR_ARG;
+    if (d->A.kind == PT_V_CONCAT && (d->A.c_split <= 0 || d->A.c_split >= d->K || d->A.c_split % 32 != 0)) return PT_ERR_ARG;
+    if (d->A.kind == PT_V_CONV && d->A.cin % 32 != 0) return PT_ERR_ARG;
   }
   const int oes_t = dtype == PT_F32 ? 4 : 2;                 // output / residual element size
   const int es = operand_es > 0 ? operand_es : oes_t;        // operand element size (1: fp8 operands, bf16 output)
@@ -1438,10 +1458,10 @@ static int build_params(const pt_gemm_desc* d, int dtype, GemmParams& p, int ope
     if (d->C2 && ((reinterpret_cast<uintptr_t>(d->C2) & 15u) || d->ldc2 % 4 != 0)) return PT_ERR_ALIGN;
   }
   // reduction extent must be whole 16-byte chunks when it lies along operand columns
-  p.M = d->M; p.N = d->N; p.K = x2 ? 3 * d->K : d->K;
-  if (x2) {       // activations read {hi, hi, lo}, weights {hi, lo, hi} (bit s of the map = plane of copy s)
-    p.A = make_vop(d->A, d->M, 3 * d->K, es, 0x4);
-    p.B = make_vop(d->B, d->N, 3 * d->K, es, 0x2);
+  p.M = d->M; p.N = d->N; p.K = x2 ? 2 * d->K : d->K;
+  if (x2) {       // virtual columns: k-tile t = [hi | lo] of logical columns 32 t .. 32 t + 31 (VOp)
+    p.A = make_vop(d->A, d->M, 2 * d->K, es, 1);
+    p.B = make_vop(d->B, d->N, 2 * d->K, es, 1);
   } else {
     p.A = d->A.trans ? make_vop(d->A, d->K, d->M, es) : make_vop(d->A, d->M, d->K, es);
     p.B = d->B.trans ? make_vop(d->B, d->K, d->N, es) : make_vop(d->B, d->N, d->K, es);
@@ -1487,7 +1507,7 @@ extern "C" int pt_gemm(const pt_gemm_desc* d, int dtype, pt_stream stream) {
   if (st != PT_OK) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PT_F32) return dispatch<float>(p, d->A.trans != 0, d->B.trans != 0, s);
-  return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);      // PT_BF16 and PT_BF16X2 (a bf16 GEMM over 3 K plane copies)
+  return dispatch<bf16_t>(p, d->A.trans != 0, d->B.trans != 0, s);      // PT_BF16 and PT_BF16X2 (plane operands: bf16 x 3 k-tiles)
 }
 
 // fp8 operands (e4m3 weights; e4m3 or e5m2 activations / gradients), bf16 output, f32 accumulation, every epilogue of pt_gemm.

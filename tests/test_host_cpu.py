@@ -182,6 +182,8 @@ def test_cabi_refuses_bad_arguments_with_a_status_never_a_launch():
     assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # a plane row holds 2 N elements
     bad = L.pt_gemm_desc.from_buffer_copy(x2); bad.x2_block = 48
     assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # the plane block must divide N
+    bad = L.pt_gemm_desc.from_buffer_copy(x2); bad.K = 72
+    assert lib.pt_gemm(ctypes.byref(bad), L.PT_BF16X2, None) == -5                  # a k-tile carries both planes of 32 columns
     assert lib.pt_gemm(ctypes.byref(x2), 7, None) == -2                             # unknown dtype
     l2 = L.pt_lstm2_desc(); l2.B, l2.T, l2.H, l2.per_step = 4, 10, 512, 1
     for f in ("x", "xg0", "whh0", "wcat1", "bias1", "h0_seq", "h1_seq", "c0", "c1", "out_elu"):
