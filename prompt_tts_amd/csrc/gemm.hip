@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const FoldGroup g) {
   }
 }
 
-// x2_map: 0 = plain storage; else PT_BF16X2 with this plane map (bit s = plane of copy s of the K columns); cols = 3 K then
+// x2_map: 0 = plain storage; else PT_BF16X2 plane rows, cols = 2 K virtual columns (see VOp)
 VOp make_vop(const pt_operand& o, int64_t rows, int64_t cols, int es, int x2_map = 0) {
   VOp v;
   v.krep = 0; v.plane1 = v.plane2 = 0; v.pmap = 0;

@@ -169,7 +169,7 @@ def run_lstm2(B, T, x, xg0, w_hh0, wcat1, bias1, pt, device, dtype, status=None,
 # wide margin) instead of the exact f32 MFMA, which runs at 1/16 of the bf16 rate.  PT_ENCODEC_F32_X3=0: exact f32 everywhere.
 F32_X3 = __import__("os").environ.get("PT_ENCODEC_F32_X3", "1") != "0"
 # ... and activations in SPLIT storage (PT_BF16X2: a row of C values = [C hi | C lo] bf16 planes, split once by the producer):
-# every GEMM is then a plain bf16 GEMM over 3 K with no conversion in its loop, and the 3 kHz -> 24 kHz end runs as the f32-class
+# a GEMM k-tile then carries both planes of 32 columns (bf16 x 3 products, no conversion in the loop), and the 3 kHz -> 24 kHz end runs as the f32-class
 # fused stage kernels (csrc/encodec_x2.hip).  PT_ENCODEC_F32_PLANES=0: f32 activations, hi / lo split inside the product loops
 # (round 3's path; kept for comparison).
 F32_PLANES = __import__("os").environ.get("PT_ENCODEC_F32_PLANES", "1") != "0"
