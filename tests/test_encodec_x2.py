@@ -30,11 +30,14 @@ def test_planes_round_trip_is_f32_class(dev):
 
 
 @pytest.mark.parametrize("M,N,K,kind", [(300, 128, 192, "plain"), (1024, 256, 512, "plain"), (225, 64, 384, "concat"),
-                                        (3 * 75, 512, 7 * 128, "conv7"), (2 * 300, 640, 2 * 256, "back2"), (2 * 96, 128, 3 * 256, "conv3")])
+                                        (3 * 75, 512, 7 * 128, "conv7"), (2 * 300, 640, 2 * 256, "back2"), (2 * 96, 128, 3 * 256, "conv3"),
+                                        (1, 8, 32, "plain"), (257, 72, 32, "plain"), (130, 136, 160, "concat"), (3 * 11, 24, 7 * 32, "conv7"),
+                                        (2 * 5, 128, 2 * 32, "back2"), (2 * 700, 256, 3 * 32, "conv3")])
 def test_gemm_x2_matches_f32(dev, M, N, K, kind):
     """pt_gemm(PT_BF16X2): plane operands (plain, channel concat, causal-reflect / back conv gathers), bias + ELU, a second ELU'd
-    output, plane-blocked output columns, f32 output; M tails and N that is not a multiple of a tile -- against torch f32 at 1e-4
-    of the output's peak (three bf16 products carry ~2^-16 per product)."""
+    output, plane-blocked output columns, f32 output; M tails and N that is not a multiple of a tile; one k-tile (K = 32), a
+    32-column segment per conv tap / concat half, items shorter than the taps reach -- against torch f32 at 1e-4 of the output's
+    peak (three bf16 products carry ~2^-16 per product)."""
     from prompt_tts_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)
     w = torch.randn(N, K, generator=g) * K ** -0.5
