@@ -82,7 +82,7 @@ __device__ __attribute__((aligned(256))) const uint32_t pt_zero_page[64] = {0};
 #define PT_GEMM_TRACE 0       // tools/gemm_probe.py --trace: wave 0 of workgroup 0 leaves s_memtime stamps in pt_trace
 #endif
 #if PT_GEMM_TRACE
-__device__ unsigned long long pt_trace[8];
+__device__ unsigned long long pt_trace[8 + 32 * 4];     // [8 ..]: per k-tile stamps of the two-stage loop (tools/gemm_probe.py --ktrace)
 #endif
 #if PT_GEMM_TRACE
 #define PT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pt_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -843,13 +843,26 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
     __syncthreads();          // hipcc drains vmcnt(0) before the barrier while LDS-DMA is outstanding
     PT_STAMP(2);
     int cur = 0;
+#if PT_GEMM_TRACE
+    __shared__ unsigned long long ktr[32 * 4];      // per k-tile: loop top, loads issued, MFMAs issued, loads landed (then the barrier)
+#define PT_KSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && kt - kt_begin < 32) ktr[(kt - kt_begin) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT_KSTAMP(i) do { } while (0)
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
+      PT_KSTAMP(0);
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+      PT_KSTAMP(1);
       compute(cur);
-      if (PT_GEMM_ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT_KSTAMP(2);
+      if (PT_GEMM_ASM_DMA || PT_GEMM_TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT_KSTAMP(3);
       __syncthreads();
       cur ^= 1;
     }
+#if PT_GEMM_TRACE
+    if (blockIdx.x == 0 && threadIdx.x < 128) pt_trace[8 + threadIdx.x] = ktr[threadIdx.x];
+#endif
   } else {
     constexpr int PER_TILE = Cfg::A_CHUNKS + Cfg::B_CHUNKS;     // LDS-DMA instructions a thread issues per k-tile
     stage(kt_begin, 0);
@@ -1542,6 +1555,9 @@ extern "C" int pt_gemm_fp8(const pt_gemm_desc* d, int a_format, const float* sca
 #if PT_GEMM_TRACE
 extern "C" int pt_debug_gemm_trace(unsigned long long* out8) {       // diagnostic builds only (tools/gemm_probe.py --trace)
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_trace), sizeof(unsigned long long) * 8) == hipSuccess ? PT_OK : PT_ERR_LAUNCH;
+}
+extern "C" int pt_debug_gemm_ktrace(unsigned long long* out136) {
+  return hipMemcpyFromSymbol(out136, HIP_SYMBOL(pt_trace), sizeof(unsigned long long) * 136) == hipSuccess ? PT_OK : PT_ERR_LAUNCH;
 }
 #endif
 

@@ -137,6 +137,28 @@ if __name__ == "__main__":
             t = [int(buf[i]) for i in range(6)]
             print(name, "stamps (x10 ns) relative to entry:", [x - t[0] for x in t], flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--ktrace":   # per k-tile stamps of the two-stage 256 x 256 kernel (PT_GEMM_TILE=512)
+        os.environ["PT_GEMM_TILE"] = os.environ.get("PT_GEMM_TILE", "512")
+        out = "/tmp/libgemm_trace.so"
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPT_GEMM_TRACE=1",
+                        os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "capi.hip"), "-o", out], check=True)
+        lib = C.CDLL(out)
+        lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
+        buf = (C.c_ulonglong * 136)()
+        for name, M, N, K in SHAPES:
+            us = run(lib, M, N, K, iters=5)
+            torch.cuda.synchronize()
+            lib.pt_debug_gemm_ktrace(buf)
+            t = [int(x) for x in buf]
+            nkt = min(K // 64, 32)
+            rows = [t[8 + 4 * k:8 + 4 * k + 4] for k in range(nkt)]
+            d = [[r[1] - r[0], r[2] - r[1], r[3] - r[2], (rows[k + 1][0] - r[3]) if k + 1 < nkt else 0] for k, r in enumerate(rows)]
+            mid = d[1:-1] or d
+            mean = [sum(x[i] for x in mid) / len(mid) for i in range(4)]
+            print(f"{name}: {us:.1f} us; prologue {t[2] - t[0]} cycles, k-loop {rows[-1][3] - rows[0][0]}, epilogue {t[5] - t[3]}; per k-tile (mean of the inner ones): "
+                  f"issue loads {mean[0]:.0f}, reads + MFMAs issued {mean[1]:.0f}, wait for the loads {mean[2]:.0f}, barrier {mean[3]:.0f}", flush=True)
+            print("   first tiles:", d[:4], flush=True)
+        sys.exit(0)
     variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]
     libs = {v: build(v) for v in variants}
     print("shape".ljust(18) + "".join(f"ab{v}:us/TF".rjust(18) for v in variants), flush=True)
