@@ -86,8 +86,11 @@ __device__ unsigned long long pt_trace[8 + 32 * 4];     // [8 ..]: per k-tile st
 #endif
 #if PT_GEMM_TRACE
 #define PT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pt_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+// the clock the kernel runs at: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) between entry and exit of workgroup 0
+#define PT_STAMP_RT(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pt_trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PT_STAMP(k) do { } while (0)
+#define PT_STAMP_RT(k) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(1))) const void pt_gptr;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
 
   if (PT_GEMM_ABLATE == 5) return;      // probe: pure dispatch cost
-  PT_STAMP(0);
+  PT_STAMP(0); PT_STAMP_RT(6);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;     // WAVES_M x WAVES_N waves of WM x 64
   const int g = lane >> 4, li = lane & 15;
@@ -909,7 +912,7 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
   // every wave is past the loop's last barrier: the operand stages are dead and serve as per-row-block transposition scratch
   static_assert(Cfg::NWAVES * MI * SCRATCH_PER_WAVE <= NSTAGE * STAGE_BYTES, "stages hold one scratch per row block per wave");
   gemm_epilogue<T, ATOMIC, MI, BM, BN, X2>(p, acc, m0, n0, wm, wn, lane, smem + wave * (MI * SCRATCH_PER_WAVE), SCRATCH_PER_WAVE);
-  PT_STAMP(5);
+  PT_STAMP(5); PT_STAMP_RT(7);
 }
 
 // =====================================================================================================================

@@ -146,7 +146,7 @@ if __name__ == "__main__":
         lib.pt_gemm.argtypes = [C.POINTER(L.pt_gemm_desc), C.c_int, C.c_void_p]; lib.pt_gemm.restype = C.c_int
         buf = (C.c_ulonglong * 136)()
         for name, M, N, K in SHAPES:
-            us = run(lib, M, N, K, iters=5)
+            us = run(lib, M, N, K, iters=200)          # long enough for the clock to settle
             torch.cuda.synchronize()
             lib.pt_debug_gemm_ktrace(buf)
             t = [int(x) for x in buf]
@@ -155,7 +155,8 @@ if __name__ == "__main__":
             d = [[r[1] - r[0], r[2] - r[1], r[3] - r[2], (rows[k + 1][0] - r[3]) if k + 1 < nkt else 0] for k, r in enumerate(rows)]
             mid = d[1:-1] or d
             mean = [sum(x[i] for x in mid) / len(mid) for i in range(4)]
-            print(f"{name}: {us:.1f} us; prologue {t[2] - t[0]} cycles, k-loop {rows[-1][3] - rows[0][0]}, epilogue {t[5] - t[3]}; per k-tile (mean of the inner ones): "
+            ghz = (t[5] - t[0]) / max(t[7] - t[6], 1) * 0.1        # shader cycles per 100 MHz tick over the life of workgroup 0
+            print(f"{name}: {us:.1f} us at {ghz:.2f} GHz (s_memtime / s_memrealtime); prologue {t[2] - t[0]} cycles, k-loop {rows[-1][3] - rows[0][0]}, epilogue {t[5] - t[3]}; per k-tile (mean of the inner ones): "
                   f"issue loads {mean[0]:.0f}, reads + MFMAs issued {mean[1]:.0f}, wait for the loads {mean[2]:.0f}, barrier {mean[3]:.0f}", flush=True)
             print("   first tiles:", d[:4], flush=True)
         sys.exit(0)
