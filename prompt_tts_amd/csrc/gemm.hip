@@ -28,7 +28,7 @@
                                 // measured neutral (round 3): unlike the attention rings, hipcc puts no alias wait into this loop
 #endif
 #ifndef PT_GEMM_ABLATE
-#define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores, 4 all three (launch floor)
+#define PT_GEMM_ABLATE 0   // tools/gemm_probe.py: 1 no MFMA/LDS reads, 2 no staging loads, 3 no epilogue stores, 4 all three (launch floor); 11: plane conv operands without the A loads of every second k-tile
 #endif
 
 namespace {
@@ -735,8 +735,10 @@ __global__ __launch_bounds__((TileCfg<BM, BN>::NTHREADS), (TileCfg<BM, BN>::MIN_
       for (int i = 0; i < Cfg::B_CHUNKS; ++i) pb[i] += stb[i];
     }
     if (PT_GEMM_ABLATE == 2 || PT_GEMM_ABLATE == 4) return;
-#pragma unroll
-    for (int i = 0; i < Cfg::A_CHUNKS; ++i) pt_dma16(pa[i], sa + (wbase + NTHREADS * i) * 16);
+    if (!(PT_GEMM_ABLATE == 11 && X2 && KA == 1 && (kt & 1))) {      // probe 11: every second k-tile without its A loads (the byte
+#pragma unroll                                                          // count of a conv operand staged once per two taps; wrong results)
+      for (int i = 0; i < Cfg::A_CHUNKS; ++i) pt_dma16(pa[i], sa + (wbase + NTHREADS * i) * 16);
+    }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) pt_dma16(pb[i], sb + (wbase + NTHREADS * i) * 16);
   };
